@@ -1,0 +1,210 @@
+/* segmi.h -- C ABI of libsegmi.so: the MI355X (gfx950) hot path behind segmantic's
+ * `segmantic-unet train / train-config / predict` surface.
+ *
+ * The reference (dyollb/segmantic) is pure Python and has no FFI of its own: its arithmetic is
+ * delegated to torch.nn / MONAI / SimpleITK.  Each entry point
+ * below therefore cites the reference *call site* whose third-party operator it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative SEGMI_E* code on failure;
+ *    segmi_last_error() returns a thread-local message for the last failure.
+ *  - all pointers are DEVICE pointers unless the name ends in _host; nothing is allocated or
+ *    freed behind the caller's back, no ownership is transferred.
+ *  - `stream` is a hipStream_t (0 = default stream); every call is asynchronous on it.
+ *  - activations are NDHWC ("channels last"): element (n,z,y,x,c) of a view lives at
+ *    data[(((n*d + z)*h + y)*w + x)*ld + c]; ld >= c allows concat-by-offset views.
+ *  - dtype: SEGMI_F32 (exact-f32 MFMA path, parity mode) or SEGMI_BF16 (bf16 storage,
+ *    f32 accumulation).
+ */
+#ifndef SEGMI_H_
+#define SEGMI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGMI_VERSION 1
+
+enum { SEGMI_F32 = 0, SEGMI_BF16 = 1 };
+enum { SEGMI_OK = 0, SEGMI_EINVAL = -1, SEGMI_EUNSUPPORTED = -2, SEGMI_ELAUNCH = -3 };
+
+/* NDHWC activation view */
+typedef struct segmi_act {
+  void* data;
+  int32_t n, d, h, w; /* batch and spatial extents            */
+  int32_t c;          /* channels of this view                */
+  int32_t ld;         /* elements between consecutive voxels  */
+} segmi_act;
+
+int segmi_version(void);
+const char* segmi_last_error(void);
+
+/* ---------------------------------------------------------------- weights -------------- */
+/* Fragment-packed weights: the layout the MFMA kernels stream as B/A operands.
+ * kind: 0 = Conv3d forward            (src = torch Conv3d weight [Cout][Cin][k][k][k])
+ *       1 = Conv3d stride-1 dgrad     (same src; flipped taps, channels transposed)
+ *       2 = transposed-conv kernel    (src = torch ConvTranspose3d weight [Cin][Cout][3][3][3],
+ *                                      or a stride-2 Conv3d weight for its dgrad)
+ * cin/cout are those of the *source* tensor's role in the kernel that will consume the pack
+ * (see DESIGN.md "weight packs").  scale (nullable, f32[cout_k]) folds a per-output-channel
+ * factor (eval-mode BatchNorm) into the weights.
+ * Replaces: weight handling inside torch.nn.Conv3d / ConvTranspose3d reached from
+ * src/segmantic/seg/monai_unet.py:114-124,221-222. */
+int64_t segmi_wpack_bytes(int dtype, int kind, int cin_k, int cout_k, int ksize);
+int segmi_wpack(int dtype, int kind, const float* w_src, const float* scale, int cin_k,
+                int cout_k, int ksize, void* packed, void* stream);
+
+/* ---------------------------------------------------------------- convolution ---------- */
+/* Conv3d k in {1,3}, stride in {1,2}, pad (k-1)/2, fused epilogue:
+ *   v = conv(in) + bias ; stats += (v, v^2) ; v = prelu(v) ; v += residual ; out = v
+ * bias f32[cout] nullable; prelu_alpha device f32* nullable; residual nullable;
+ * stats_partials nullable: f32[segmi_conv3d_stats_rows(...)][2][cout] per-workgroup partial
+ * sums of v and v^2 over valid voxels (deterministic; reduced by segmi_bn_finalize).
+ * MFMA path needs cin % 16 == 0 and cout % 16 == 0 with a kind-0/1 pack; otherwise pass
+ * packed = NULL and w_src = torch-layout f32 weights for the direct kernel.
+ * Replaces torch.nn.Conv3d under monai UNet, src/segmantic/seg/monai_unet.py:114-124,341. */
+int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                            int stride);
+int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
+                     const float* w_src, int w_kind, const float* bias,
+                     const float* prelu_alpha, const segmi_act* residual,
+                     float* stats_partials, int ksize, int stride, void* stream);
+
+/* ConvTranspose3d k3 s2 p1 (output extent 2*in or 2*in-1 per dim, taken from `out`),
+ * same fused epilogue.  Also the dgrad of a stride-2 Conv3d.
+ * Replaces torch.nn.ConvTranspose3d, src/segmantic/seg/monai_unet.py:114-124. */
+int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out);
+int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
+                      const float* w_src, const float* bias, const float* prelu_alpha,
+                      const segmi_act* residual, float* stats_partials, void* stream);
+
+/* Weight gradient of a Conv3d (k, stride as forward): dw[co][ci][tap] (torch layout, f32) and
+ * db[co] (nullable) from x (forward input) and dy (grad of the conv output).  Two-stage
+ * deterministic reduction through `workspace` (>= segmi_conv3d_wgrad_workspace bytes).
+ * The ConvTranspose3d weight gradient is the same call with x := dy_T, dy := x_T (stride 2).
+ * Replaces autograd's conv backward reached from manual_backward,
+ * src/segmantic/seg/monai_unet.py:345. */
+int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_act* dy,
+                                     int ksize, int stride);
+int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
+                       float* db, int ksize, int stride, void* workspace, void* stream);
+/* bias gradient only: db[c] = sum over voxels of dy */
+int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------- norm + activation ---- */
+/* BatchNorm3d (training statistics) + PReLU, MONAI ADN "NDA" ordering.
+ * Replaces torch.nn.BatchNorm3d / PReLU under monai ADN, monai_unet.py:114-124. */
+int segmi_bn_stats_rows(const segmi_act* x);
+int segmi_bn_stats(int dtype, const segmi_act* x, float* stats_partials, void* stream);
+/* partials f32[rows][2][c] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
+ * running_mean/var (nullable) updated with `momentum` and the unbiased variance. */
+int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count,
+                      const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, float* mean,
+                      float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics */
+int segmi_bn_eval_affine(int c, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps,
+                         float* scale, float* shift, void* stream);
+/* y = prelu(x*scale + shift) + residual   (alpha nullable -> identity, residual nullable) */
+int segmi_bn_act_fwd(int dtype, const segmi_act* x, const segmi_act* y, const float* scale,
+                     const float* shift, const float* prelu_alpha, const segmi_act* residual,
+                     void* stream);
+/* backward of y = prelu(bn(x)):  pass 1 reduces, finalize, pass 2 writes dx.
+ * red_partials f32[rows][3][c]: sum dz, sum dz*xhat, sum dy*z*[z<=0]  (dz = dy*prelu'(z)) */
+int segmi_bn_act_bwd_rows(const segmi_act* x);
+int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
+                            const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* prelu_alpha, float* red_partials,
+                            void* stream);
+int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double count,
+                              const float* gamma, const float* invstd, float* dgamma,
+                              float* dbeta, float* dalpha, float* coef, void* stream);
+int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
+                           const segmi_act* dx, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, const float* prelu_alpha,
+                           const float* coef, void* stream);
+
+/* elementwise helpers on NDHWC views */
+int segmi_add(int dtype, const segmi_act* a, const segmi_act* b, const segmi_act* out,
+              void* stream);                       /* out = a + b (b nullable -> copy)        */
+int segmi_cast_copy(int src_dtype, const segmi_act* src, int dst_dtype, const segmi_act* dst,
+                    void* stream);                 /* dtype / ld converting copy              */
+int segmi_nchw_to_ndhwc(const float* src, int dst_dtype, const segmi_act* dst, void* stream);
+int segmi_ndhwc_to_nchw(int src_dtype, const segmi_act* src, float* dst, void* stream);
+
+/* ---------------------------------------------------------------- loss + optimiser ----- */
+/* MONAI DiceLoss(to_onehot_y=True, softmax=True), monai_unet.py:128,344.
+ * labels: f32[n*d*h*w] integer-valued class ids.  partials f32[n][chunks][3][k];
+ * coef f32[n][2][k] receives the backward coefficients; loss f32[1]. */
+int segmi_dice_chunks(const segmi_act* logits);
+int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labels,
+                           float* partials, float* coef, float* loss, float smooth_nr,
+                           float smooth_dr, void* stream);
+int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labels,
+                           const float* coef, float grad_scale, const segmi_act* dlogits,
+                           void* stream);
+
+/* torch.optim.Adam / SGD semantics over one flat f32 arena, monai_unet.py:292-304,346.
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int segmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    float* max_exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, float grad_scale,
+                    void* stream);
+int segmi_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                   float momentum, float weight_decay, int first_step, float grad_scale,
+                   void* stream);
+int segmi_adabelief_step(float* param, const float* grad, float* exp_avg, float* exp_avg_var,
+                         int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int weight_decouple, int64_t step,
+                         float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------- sliding window ------- */
+/* MONAI sliding_window_inference, monai_unet.py:354-356,637-639,665.
+ * starts_host: int32[nwin][3] (z,y,x) window origins in the (padded) image. */
+int segmi_sw_gather(int dtype_src, const segmi_act* image, int img_index,
+                    const int32_t* starts_host, int nwin, int dst_dtype,
+                    const segmi_act* windows, void* stream);
+/* acc[z,y,x,k] += w * pred ; cnt[z,y,x] += w  for each window in order (deterministic).
+ * importance nullable (constant 1) else f32[roi_d*roi_h*roi_w]. cnt nullable. */
+int segmi_sw_scatter_add(int dtype, const segmi_act* pred, const int32_t* starts_host,
+                         int nwin, const float* importance, const segmi_act* acc, float* cnt,
+                         void* stream);
+/* logits = acc / cnt (in place, nullable skip) and labels = argmax_k (first max wins).
+ * label_bytes in {1,2,4}. */
+int segmi_sw_finalize(const segmi_act* acc, const float* cnt, int write_logits, void* labels,
+                      int label_bytes, void* stream);
+/* AsDiscrete(argmax=True), monai_unet.py:129-134,622,673 */
+int segmi_argmax(int dtype, const segmi_act* logits, void* labels, int label_bytes,
+                 void* stream);
+/* per-class overlap counts for DiceMetric (monai_unet.py:136-138): counts i64[k][3] =
+ * |pred==c & true==c|, |pred==c|, |true==c| ; labels are int32 */
+int segmi_label_counts(const int32_t* pred, const int32_t* truth, int64_t n, int k,
+                       int64_t* counts, void* stream);
+
+/* ---------------------------------------------------------------- image ops ------------ */
+/* ITK ResampleImageFilter replacement, src/segmantic/image/processing.py:49-120.
+ * index_map_host: 12 doubles, row-major 3x4 affine taking an output index (x,y,z,1) to the
+ * continuous input index (x,y,z).  pixel: 0=f32 1=u8 2=i16 3=i32 4=u16.  Arrays are [z][y][x].
+ * interp: 0 = linear, 1 = nearest. */
+int segmi_resample3d(int pixel, const void* src, int sx, int sy, int sz, void* dst, int dx,
+                     int dy, int dz, const double* index_map_host, int interp,
+                     double default_value, void* stream);
+/* NormalizeIntensityd(channel_wise=True), monai_unet.py:164: in-place (x-mean)/std per channel
+ * of a [c][nvox] f32 array.  workspace >= segmi_normalize_workspace(c, nvox) bytes. */
+int64_t segmi_normalize_workspace(int c, int64_t nvox);
+int segmi_normalize_intensity(float* x, int c, int64_t nvox, void* workspace, void* stream);
+/* on-device patch sampler: copies `count` roi-sized crops (origins in starts_host, int32
+ * [count][4] = n,z,y,x) of image (f32 -> dst dtype) and label (f32) volumes; per-axis flips
+ * from flips_host (uint8[count], bit0=z bit1=y bit2=x).  monai_unet.py:193-217. */
+int segmi_crop_patches(const segmi_act* image, const float* label, const int32_t* starts_host,
+                       const uint8_t* flips_host, int count, int dst_dtype,
+                       const segmi_act* out_image, float* out_label, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGMI_H_ */

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libsegmi.so`` (the C-ABI declared in ``include/segmi.h``).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  Importing this module
+raises ``ImportError`` when the shared object is missing or does not export the full ABI, and
+every call raises ``RuntimeError`` with ``segmi_last_error()`` when the native side fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+SEGMI_F32 = 0
+SEGMI_BF16 = 1
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libsegmi.so"
+
+
+class Act(C.Structure):
+    """``segmi_act``: NDHWC activation view."""
+
+    _fields_ = [("data", C.c_void_p), ("n", C.c_int32), ("d", C.c_int32), ("h", C.c_int32),
+                ("w", C.c_int32), ("c", C.c_int32), ("ld", C.c_int32)]
+
+
+_P = C.c_void_p
+_AP = C.POINTER(Act)
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+_d = C.c_double
+
+# name -> (restype, argtypes); mirrors include/segmi.h one to one
+SIGNATURES = {
+    "segmi_version": (_i, []),
+    "segmi_last_error": (C.c_char_p, []),
+    "segmi_wpack_bytes": (_i64, [_i, _i, _i, _i, _i]),
+    "segmi_wpack": (_i, [_i, _i, _P, _P, _i, _i, _i, _P, _P]),
+    "segmi_conv3d_stats_rows": (_i, [_i, _AP, _AP, _i, _i]),
+    "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, _P]),
+    "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),
+    "segmi_convT3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P]),
+    "segmi_conv3d_wgrad_workspace": (_i64, [_i, _AP, _AP, _i, _i]),
+    "segmi_conv3d_wgrad": (_i, [_i, _AP, _AP, _P, _P, _i, _i, _P, _P]),
+    "segmi_bias_grad": (_i, [_i, _AP, _P, _P, _P]),
+    "segmi_bn_stats_rows": (_i, [_AP]),
+    "segmi_bn_stats": (_i, [_i, _AP, _P, _P]),
+    "segmi_bn_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P]),
+    "segmi_bn_eval_affine": (_i, [_i, _P, _P, _P, _P, _f, _P, _P, _P]),
+    "segmi_bn_act_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _AP, _P]),
+    "segmi_bn_act_bwd_rows": (_i, [_AP]),
+    "segmi_bn_act_bwd_reduce": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P, _P]),
+    "segmi_bn_act_bwd_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _P, _P, _P]),
+    "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _P]),
+    "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),
+    "segmi_cast_copy": (_i, [_i, _AP, _i, _AP, _P]),
+    "segmi_nchw_to_ndhwc": (_i, [_P, _i, _AP, _P]),
+    "segmi_ndhwc_to_nchw": (_i, [_i, _AP, _P, _P]),
+    "segmi_dice_chunks": (_i, [_AP]),
+    "segmi_softmax_dice_fwd": (_i, [_i, _AP, _P, _P, _P, _P, _f, _f, _P]),
+    "segmi_softmax_dice_bwd": (_i, [_i, _AP, _P, _P, _f, _AP, _P]),
+    "segmi_adam_step": (_i, [_P, _P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i64, _f, _P]),
+    "segmi_sgd_step": (_i, [_P, _P, _P, _i64, _f, _f, _f, _i, _f, _P]),
+    "segmi_adabelief_step": (_i, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i, _i64, _f, _P]),
+    "segmi_sw_gather": (_i, [_i, _AP, _i, _P, _i, _i, _AP, _P]),
+    "segmi_sw_scatter_add": (_i, [_i, _AP, _P, _i, _P, _AP, _P, _P]),
+    "segmi_sw_finalize": (_i, [_AP, _P, _i, _P, _i, _P]),
+    "segmi_argmax": (_i, [_i, _AP, _P, _i, _P]),
+    "segmi_label_counts": (_i, [_P, _P, _i64, _i, _P, _P]),
+    "segmi_resample3d": (_i, [_i, _P, _i, _i, _i, _P, _i, _i, _i, _P, _i, _d, _P]),
+    "segmi_normalize_workspace": (_i64, [_i, _i64]),
+    "segmi_normalize_intensity": (_i, [_P, _i, _i64, _P, _P]),
+    "segmi_crop_patches": (_i, [_AP, _P, _P, _P, _i, _i, _AP, _P, _P]),
+}
+
+
+def _load():
+    path = Path(os.environ.get("SEGMI_LIB", str(_LIB_PATH)))
+    if not path.exists():
+        raise ImportError(
+            f"segmantic_amd: native library {path} not found. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C segmantic_amd/csrc`. "
+            f"There is no CPU fallback.")
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # pragma: no cover
+        raise ImportError(f"segmantic_amd: cannot load {path}: {e}") from e
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise ImportError(f"segmantic_amd: {path} lacks symbols {missing}; rebuild it")
+    return lib, path
+
+
+lib, LIB_PATH = _load()
+
+
+def last_error() -> str:
+    return lib.segmi_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libsegmi {what} failed (code {rc}): {last_error()}")

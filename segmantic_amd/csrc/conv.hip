@@ -1,0 +1,256 @@
+// conv.hip -- C entry points for Conv3d / ConvTranspose3d forward + the direct (non-MFMA)
+// kernels used when a channel count is not a multiple of 16 (first layer Cin=1, K=3 heads,
+// tiny test networks).
+#include "conv_fwd_impl.h"
+#include "convt_fwd_impl.h"
+
+namespace segmi {
+
+int conv_mfma_f32(const ConvParams& p, int ksize, int stride, hipStream_t st);
+int conv_mfma_bf16(const ConvParams& p, int ksize, int stride, hipStream_t st);
+int convt_mfma_f32(const ConvTParams& p, hipStream_t st);
+int convt_mfma_bf16(const ConvTParams& p, hipStream_t st);
+int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
+int bn_stats_rows_for(const segmi_act* x);
+
+struct DirectParams {
+  const void* in;
+  void* out;
+  const float* w;
+  const float* bias;
+  const float* alpha;
+  const void* res;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, ldi, ldo, ldr;
+  int ks, stride, kind;
+};
+
+// one thread per (voxel, co); co fastest so stores coalesce along NDHWC rows.
+// kind 0: w[co][ci][tap]; kind 1 (stride-1 dgrad): w[ci][co][flipped tap]
+template <typename T>
+__global__ void conv_direct_kernel(DirectParams p) {
+  const int64_t total = (int64_t)p.N * p.Do * p.Ho * p.Wo * p.Cout;
+  const int pad = (p.ks - 1) / 2, nt = p.ks * p.ks * p.ks;
+  const T* in = (const T*)p.in;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int co = e % p.Cout;
+    int64_t v = e / p.Cout;
+    const int ox = v % p.Wo; v /= p.Wo;
+    const int oy = v % p.Ho; v /= p.Ho;
+    const int oz = v % p.Do;
+    const int n = v / p.Do;
+    float acc = 0.f;
+    for (int kd = 0; kd < p.ks; ++kd) {
+      const int z = oz * p.stride - pad + kd;
+      if ((unsigned)z >= (unsigned)p.Di) continue;
+      for (int kh = 0; kh < p.ks; ++kh) {
+        const int y = oy * p.stride - pad + kh;
+        if ((unsigned)y >= (unsigned)p.Hi) continue;
+        for (int kw = 0; kw < p.ks; ++kw) {
+          const int x = ox * p.stride - pad + kw;
+          if ((unsigned)x >= (unsigned)p.Wi) continue;
+          const int tap = (kd * p.ks + kh) * p.ks + kw;
+          const T* ip = in + ((((int64_t)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi;
+          if (p.kind == 0) {
+            const float* wp = p.w + ((int64_t)co * p.Cin) * nt + tap;
+            for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(Elem<T>::ld(ip + ci), wp[(int64_t)ci * nt], acc);
+          } else {
+            const float* wp = p.w + (int64_t)co * nt + (nt - 1 - tap);
+            for (int ci = 0; ci < p.Cin; ++ci)
+              acc = fmaf(Elem<T>::ld(ip + ci), wp[(int64_t)ci * p.Cout * nt], acc);
+          }
+        }
+      }
+    }
+    if (p.bias) acc += p.bias[co];
+    if (p.alpha) acc = acc > 0.f ? acc : (*p.alpha) * acc;
+    const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    if (p.res) acc += Elem<T>::ld((const T*)p.res + vox * p.ldr + co);
+    Elem<T>::st((T*)p.out + vox * p.ldo + co, acc);
+  }
+}
+
+// transposed conv k3 s2 p1, w[ci][co][27]
+template <typename T>
+__global__ void convt_direct_kernel(DirectParams p) {
+  const int64_t total = (int64_t)p.N * p.Do * p.Ho * p.Wo * p.Cout;
+  const T* in = (const T*)p.in;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int co = e % p.Cout;
+    int64_t v = e / p.Cout;
+    const int ox = v % p.Wo; v /= p.Wo;
+    const int oy = v % p.Ho; v /= p.Ho;
+    const int oz = v % p.Do;
+    const int n = v / p.Do;
+    float acc = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+      const int tz = oz + 1 - kd;
+      if (tz < 0 || (tz & 1) || (tz >> 1) >= p.Di) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ty = oy + 1 - kh;
+        if (ty < 0 || (ty & 1) || (ty >> 1) >= p.Hi) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tx = ox + 1 - kw;
+          if (tx < 0 || (tx & 1) || (tx >> 1) >= p.Wi) continue;
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          const T* ip = in + ((((int64_t)n * p.Di + (tz >> 1)) * p.Hi + (ty >> 1)) * p.Wi + (tx >> 1)) * p.ldi;
+          const float* wp = p.w + (int64_t)co * 27 + tap;
+          for (int ci = 0; ci < p.Cin; ++ci)
+            acc = fmaf(Elem<T>::ld(ip + ci), wp[(int64_t)ci * p.Cout * 27], acc);
+        }
+      }
+    }
+    if (p.bias) acc += p.bias[co];
+    if (p.alpha) acc = acc > 0.f ? acc : (*p.alpha) * acc;
+    const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    if (p.res) acc += Elem<T>::ld((const T*)p.res + vox * p.ldr + co);
+    Elem<T>::st((T*)p.out + vox * p.ldo + co, acc);
+  }
+}
+
+static inline bool mfma_ok(int cin, int cout) { return cin % 16 == 0 && cout % 16 == 0; }
+
+static inline int out_extent(int in, int ks, int stride) {
+  const int pad = (ks - 1) / 2;
+  return (in + 2 * pad - ks) / stride + 1;
+}
+
+}  // namespace segmi
+
+using namespace segmi;
+
+extern "C" {
+
+int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                            int stride) {
+  (void)dtype; (void)ksize;
+  if (!in || !out) return 0;
+  if (mfma_ok(in->c, out->c)) return conv_mfma_rows(out, stride);
+  return bn_stats_rows_for(out);
+}
+
+int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
+                     const float* w_src, int w_kind, const float* bias,
+                     const float* prelu_alpha, const segmi_act* residual,
+                     float* stats_partials, int ksize, int stride, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "conv3d: bad dtype %d", dtype);
+  SEGMI_CHECK_ARG(act_ok(in) && act_ok(out), "conv3d: bad activation view");
+  SEGMI_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2),
+                  "conv3d: unsupported ksize/stride %d/%d", ksize, stride);
+  SEGMI_CHECK_ARG(!(ksize == 1 && stride != 1), "conv3d: k1 is stride 1 only");
+  SEGMI_CHECK_ARG(in->n == out->n && out->d == out_extent(in->d, ksize, stride) &&
+                      out->h == out_extent(in->h, ksize, stride) &&
+                      out->w == out_extent(in->w, ksize, stride),
+                  "conv3d: output extent [%d,%d,%d,%d] does not match input [%d,%d,%d,%d] k%d s%d",
+                  out->n, out->d, out->h, out->w, in->n, in->d, in->h, in->w, ksize, stride);
+  if (residual)
+    SEGMI_CHECK_ARG(act_ok(residual) && residual->n == out->n && residual->d == out->d &&
+                        residual->h == out->h && residual->w == out->w && residual->c == out->c,
+                    "conv3d: residual shape mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  const int es = dtype_size(dtype);
+  if (mfma_ok(in->c, out->c)) {
+    SEGMI_CHECK_ARG(packed, "conv3d: MFMA path needs a fragment-packed weight (segmi_wpack)");
+    SEGMI_CHECK_ARG(in->ld % (16 / es) == 0 && out->ld % 4 == 0 &&
+                        ((uintptr_t)in->data % 16) == 0 && ((uintptr_t)out->data % (4 * es)) == 0,
+                    "conv3d: MFMA path needs 16-byte aligned input rows");
+    if (residual)
+      SEGMI_CHECK_ARG(residual->ld % 4 == 0 && ((uintptr_t)residual->data % (4 * es)) == 0,
+                      "conv3d: residual rows must be 4-element aligned");
+    ConvParams p{};
+    p.in = in->data; p.out = out->data; p.wfrag = packed; p.bias = bias; p.alpha = prelu_alpha;
+    p.res = residual ? residual->data : nullptr; p.stats = stats_partials;
+    p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w;
+    p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
+    p.Cin = in->c; p.Cout = out->c; p.ldi = in->ld; p.ldo = out->ld;
+    p.ldr = residual ? residual->ld : 0;
+    p.nchunks = in->c / pick_ck(dtype, in->c);
+    p.ntiles_total = out->c / 16;
+    return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st)
+                              : conv_mfma_bf16(p, ksize, stride, st);
+  }
+  SEGMI_CHECK_ARG(w_src, "conv3d: direct path (channels not multiples of 16) needs w_src");
+  SEGMI_CHECK_ARG(w_kind == 0 || w_kind == 1, "conv3d: bad w_kind %d", w_kind);
+  DirectParams p{};
+  p.in = in->data; p.out = out->data; p.w = w_src; p.bias = bias; p.alpha = prelu_alpha;
+  p.res = residual ? residual->data : nullptr;
+  p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h;
+  p.Wo = out->w; p.Cin = in->c; p.Cout = out->c; p.ldi = in->ld; p.ldo = out->ld;
+  p.ldr = residual ? residual->ld : 0; p.ks = ksize; p.stride = stride; p.kind = w_kind;
+  const int64_t total = act_voxels(out) * out->c;
+  int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  if (dtype == SEGMI_F32) hipLaunchKernelGGL(conv_direct_kernel<float>, blocks, 256, 0, st, p);
+  else hipLaunchKernelGGL(conv_direct_kernel<bf16_t>, blocks, 256, 0, st, p);
+  SEGMI_LAUNCH_CHECK("conv3d_fwd(direct)");
+  if (stats_partials) {
+    SEGMI_CHECK_ARG(!prelu_alpha && !residual,
+                    "conv3d: fused statistics are taken before PReLU/residual");
+    return bn_stats_launch(dtype, out, stats_partials, st);
+  }
+  return SEGMI_OK;
+}
+
+int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out) {
+  (void)dtype;
+  if (!in || !out) return 0;
+  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(in);
+  return bn_stats_rows_for(out);
+}
+
+int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
+                      const float* w_src, const float* bias, const float* prelu_alpha,
+                      const segmi_act* residual, float* stats_partials, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "convT3d: bad dtype %d", dtype);
+  SEGMI_CHECK_ARG(act_ok(in) && act_ok(out), "convT3d: bad activation view");
+  SEGMI_CHECK_ARG(in->n == out->n, "convT3d: batch mismatch");
+  const int di[3] = {in->d, in->h, in->w}, dout[3] = {out->d, out->h, out->w};
+  for (int k = 0; k < 3; ++k)
+    SEGMI_CHECK_ARG(dout[k] == 2 * di[k] || dout[k] == 2 * di[k] - 1,
+                    "convT3d: output extent %d must be 2*in or 2*in-1 (in %d)", dout[k], di[k]);
+  if (residual)
+    SEGMI_CHECK_ARG(act_ok(residual) && residual->n == out->n && residual->d == out->d &&
+                        residual->h == out->h && residual->w == out->w && residual->c == out->c,
+                    "convT3d: residual shape mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  const int es = dtype_size(dtype);
+  if (mfma_ok(in->c, out->c)) {
+    SEGMI_CHECK_ARG(packed, "convT3d: MFMA path needs a kind-2 fragment pack (segmi_wpack)");
+    SEGMI_CHECK_ARG(in->ld % (16 / es) == 0 && out->ld % 4 == 0 &&
+                        ((uintptr_t)in->data % 16) == 0 && ((uintptr_t)out->data % (4 * es)) == 0,
+                    "convT3d: MFMA path needs 16-byte aligned input rows");
+    if (residual)
+      SEGMI_CHECK_ARG(residual->ld % 4 == 0 && ((uintptr_t)residual->data % (4 * es)) == 0,
+                      "convT3d: residual rows must be 4-element aligned");
+    ConvTParams p{};
+    p.in = in->data; p.out = out->data; p.wfrag = packed; p.bias = bias; p.alpha = prelu_alpha;
+    p.res = residual ? residual->data : nullptr; p.stats = stats_partials;
+    p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w;
+    p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
+    p.Cin = in->c; p.Cout = out->c; p.ldi = in->ld; p.ldo = out->ld;
+    p.ldr = residual ? residual->ld : 0;
+    p.nchunks = in->c / pick_ck(dtype, in->c);
+    p.ntiles_total = out->c / 16;
+    return dtype == SEGMI_F32 ? convt_mfma_f32(p, st) : convt_mfma_bf16(p, st);
+  }
+  SEGMI_CHECK_ARG(w_src, "convT3d: direct path (channels not multiples of 16) needs w_src");
+  DirectParams p{};
+  p.in = in->data; p.out = out->data; p.w = w_src; p.bias = bias; p.alpha = prelu_alpha;
+  p.res = residual ? residual->data : nullptr;
+  p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h;
+  p.Wo = out->w; p.Cin = in->c; p.Cout = out->c; p.ldi = in->ld; p.ldo = out->ld;
+  p.ldr = residual ? residual->ld : 0; p.ks = 3; p.stride = 2; p.kind = 2;
+  const int64_t total = act_voxels(out) * out->c;
+  int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  if (dtype == SEGMI_F32) hipLaunchKernelGGL(convt_direct_kernel<float>, blocks, 256, 0, st, p);
+  else hipLaunchKernelGGL(convt_direct_kernel<bf16_t>, blocks, 256, 0, st, p);
+  SEGMI_LAUNCH_CHECK("convT3d_fwd(direct)");
+  if (stats_partials) {
+    SEGMI_CHECK_ARG(!prelu_alpha && !residual,
+                    "convT3d: fused statistics are taken before PReLU/residual");
+    return bn_stats_launch(dtype, out, stats_partials, st);
+  }
+  return SEGMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// convt_fwd_impl.h -- MFMA ConvTranspose3d k3 s2 p1 forward (also the dgrad of a stride-2 conv).
+//
+// out[o] = sum_{i,k : o = 2i - 1 + k} in[i] * W[k].  Per dim an even output (r=0) takes the
+// single tap k=1 of input i=o/2; an odd output (r=1) takes k=2 of i=(o-1)/2 and k=0 of
+// i=(o+1)/2.  So the 8 output-parity classes are 8 small GEMMs with 1,2,2,4,2,4,4,8 taps (27
+// in total) over the SAME input tile -- no zero insertion, no wasted MACs.
+//
+// One workgroup stages an input tile of 64 voxels (+1 halo on the high side) per channel
+// chunk; the 4 waves split the 8 classes {7} {3,5} {6,1,0} {2,4} (8/8/7/4 taps), each wave
+// reusing its weight fragments across the 4 voxel tiles.  D[co][vox] orientation and epilogue
+// as in conv_fwd_impl.h; voxel (z,y,x) of class (rd,rh,rw) lands at (2z+rd, 2y+rh, 2x+rw).
+#pragma once
+#include "common.h"
+
+namespace segmi {
+
+struct ConvTParams {
+  const void* in;
+  void* out;
+  const void* wfrag;
+  const float* bias;
+  const float* alpha;
+  const void* res;
+  float* stats;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, ldi, ldo, ldr;
+  int tz, ty, tx;
+  int nchunks, ntiles_total;
+  int64_t class_off[8];  // byte offsets of each class in the pack
+};
+
+constexpr int kCtCls[4][3] = {{7, 0, 0}, {3, 5, 0}, {6, 1, 0}, {2, 4, 0}};
+constexpr int kCtNCls[4] = {1, 2, 3, 2};
+
+constexpr int ct_ntaps_c(int p) {
+  return (1 + ((p >> 2) & 1)) * (1 + ((p >> 1) & 1)) * (1 + (p & 1));
+}
+// row offset (in halo rows) of tap t of class p
+constexpr int ct_tap_rowoff(int p, int t, int HH, int HW) {
+  const int rw = p & 1, rh = (p >> 1) & 1, rd = (p >> 2) & 1;
+  const int nw = 1 + rw, nh = 1 + rh;
+  const int tw = t % nw, th = (t / nw) % nh, td = t / (nw * nh);
+  const int dw = rw ? tw : 0, dh = rh ? th : 0, dd = rd ? td : 0;
+  return (dd * HH + dh) * HW + dw;
+}
+
+template <typename T, int CK, int TD, int TH, int TW>
+struct ConvTGeom {
+  static constexpr int KG = Elem<T>::KG;
+  static constexpr int SPT = CK / KG;
+  static constexpr int HD = TD + 1, HH = TH + 1, HW = TW + 1;
+  static constexpr int RAWB = CK * (int)sizeof(T);
+  static constexpr int ROWB = RAWB == 32 ? 32 : RAWB + 16;
+  static constexpr int CPR = RAWB / 16;
+  static constexpr int NVT = TD * TH * TW / 16;
+  static constexpr int LDS_BYTES = HD * HH * HW * ROWB;
+  static_assert(NVT == 4, "transposed-conv tile is 64 input voxels");
+  static_assert(SPT == 2 || SPT == 4, "unsupported chunk width");
+};
+
+template <typename T, int CK, int NT, int TD, int TH, int TW, int W>
+__device__ __forceinline__ void convt_wave_compute(f32x4 (&acc)[3][4][NT], const char* smem,
+                                                   const int (&vaddr)[4], const char* wfrag,
+                                                   const ConvTParams& p, int c, int nt0,
+                                                   int lane, int g) {
+  using G = ConvTGeom<T, CK, TD, TH, TW>;
+#pragma unroll
+  for (int ci = 0; ci < kCtNCls[W]; ++ci) {
+    const int cls = kCtCls[W][ci];
+    const int ntp = ct_ntaps_c(cls);
+    const int nsteps = (ntp * G::SPT + 3) / 4;
+    const char* wb = wfrag + p.class_off[cls] +
+                     (((int64_t)c * nsteps) * p.ntiles_total + nt0) * 1024 + lane * 16;
+#pragma unroll
+    for (int s = 0; s < nsteps; ++s) {
+      int loff;
+      if constexpr (G::SPT == 2) {
+        const int t0 = 2 * s, t1 = 2 * s + 1;
+        const int o0 = ct_tap_rowoff(cls, t0, G::HH, G::HW);
+        const int o1 = t1 < ntp ? ct_tap_rowoff(cls, t1, G::HH, G::HW) : 0;
+        loff = ((g >> 1) ? o1 : o0) * G::ROWB + (g & 1) * 16;
+      } else {
+        const int tap = (4 * s) / G::SPT;
+        const int sub0 = (4 * s) % G::SPT;
+        loff = ct_tap_rowoff(cls, tap, G::HH, G::HW) * G::ROWB + (sub0 + g) * 16;
+      }
+      frag_t wf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wf[j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
+#pragma unroll
+      for (int vt = 0; vt < 4; ++vt) {
+        const frag_t a = *reinterpret_cast<const frag_t*>(smem + vaddr[vt] + loff);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[ci][vt][j] = mma16<T>(wf[j], a, acc[ci][vt][j]);
+      }
+    }
+  }
+}
+
+template <typename T, int NT, int TD, int TH, int TW, int W>
+__device__ __forceinline__ void convt_wave_store(const f32x4 (&acc)[3][4][NT],
+                                                 const ConvTParams& p, int n, int iz0, int iy0,
+                                                 int ix0, int nt0, int g, int r,
+                                                 f32x4 (&ssum)[NT], f32x4 (&ssq)[NT]) {
+  f32x4 bias4[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + (nt0 + j) * 16 + 4 * g);
+  }
+  const bool has_alpha = p.alpha != nullptr;
+  const float alpha = has_alpha ? *p.alpha : 0.f;
+  T* outp = (T*)p.out;
+  const T* resp = (const T*)p.res;
+#pragma unroll
+  for (int ci = 0; ci < kCtNCls[W]; ++ci) {
+    const int cls = kCtCls[W][ci];
+    const int rw = cls & 1, rh = (cls >> 1) & 1, rd = (cls >> 2) & 1;
+#pragma unroll
+    for (int vt = 0; vt < 4; ++vt) {
+      const int idx = vt * 16 + r;
+      const int oz = 2 * (iz0 + idx / (TW * TH)) + rd;
+      const int oy = 2 * (iy0 + (idx / TW) % TH) + rh;
+      const int ox = 2 * (ix0 + idx % TW) + rw;
+      const bool valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
+      const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v = acc[ci][vt][j] + bias4[j];
+        if (valid) {
+          if (p.stats) {
+            ssum[j] += v;
+            ssq[j] += v * v;
+          }
+          if (has_alpha) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+          }
+          const int co = (nt0 + j) * 16 + 4 * g;
+          if (resp) v += load4<T>(resp + vox * p.ldr + co);
+          store4<T>(outp + vox * p.ldo + co, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int CK, int NT, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
+  using G = ConvTGeom<T, CK, TD, TH, TW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+
+  int t = blockIdx.x;
+  const int txi = t % p.tx; t /= p.tx;
+  const int tyi = t % p.ty; t /= p.ty;
+  const int tzi = t % p.tz;
+  const int n = t / p.tz;
+  const int iz0 = tzi * TD, iy0 = tyi * TH, ix0 = txi * TW;
+  const int nt0 = blockIdx.y * NT;
+
+  f32x4 acc[3][4][NT];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[a][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int vaddr[4];
+#pragma unroll
+  for (int vt = 0; vt < 4; ++vt) {
+    const int idx = vt * 16 + r;
+    const int x = idx % TW, y = (idx / TW) % TH, z = idx / (TW * TH);
+    vaddr[vt] = ((z * G::HH + y) * G::HW + x) * G::ROWB;
+  }
+
+  const char* inb = (const char*)p.in;
+  const char* wfrag = (const char*)p.wfrag;
+  for (int c = 0; c < p.nchunks; ++c) {
+    if (c > 0) __syncthreads();
+    for (int i = tid; i < G::HD * G::HH * G::HW * G::CPR; i += 256) {
+      const int v = i / G::CPR, ch = i % G::CPR;
+      const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
+      const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
+      frag_t val = frag_t{0u, 0u, 0u, 0u};
+      if (z < p.Di && y < p.Hi && x < p.Wi) {
+        const int64_t e = ((((int64_t)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi + c * CK;
+        val = *reinterpret_cast<const frag_t*>(inb + e * (int64_t)sizeof(T) + ch * 16);
+      }
+      *reinterpret_cast<frag_t*>(smem + v * G::ROWB + ch * 16) = val;
+    }
+    __syncthreads();
+    if (wave == 0) convt_wave_compute<T, CK, NT, TD, TH, TW, 0>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
+    else if (wave == 1) convt_wave_compute<T, CK, NT, TD, TH, TW, 1>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
+    else if (wave == 2) convt_wave_compute<T, CK, NT, TD, TH, TW, 2>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
+    else convt_wave_compute<T, CK, NT, TD, TH, TW, 3>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
+  }
+
+  f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    ssum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (wave == 0) convt_wave_store<T, NT, TD, TH, TW, 0>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
+  else if (wave == 1) convt_wave_store<T, NT, TD, TH, TW, 1>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
+  else if (wave == 2) convt_wave_store<T, NT, TD, TH, TW, 2>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
+  else convt_wave_store<T, NT, TD, TH, TW, 3>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
+
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = row16_sum(ssum[j][e]);
+        const float b = row16_sum(ssq[j][e]);
+        if (r == 0) {
+          red[(wave * 2 + 0) * NT * 16 + j * 16 + 4 * g + e] = a;
+          red[(wave * 2 + 1) * NT * 16 + j * 16 + 4 * g + e] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * NT * 16) {
+      const int which = tid / (NT * 16), ch = tid % (NT * 16);
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
+      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
+    }
+  }
+}
+
+template <typename T, int CK, int NT, int TD, int TH, int TW>
+static int launch_convt_cfg(ConvTParams p, hipStream_t st) {
+  using G = ConvTGeom<T, CK, TD, TH, TW>;
+  p.tz = cdiv(p.Di, TD);
+  p.ty = cdiv(p.Hi, TH);
+  p.tx = cdiv(p.Wi, TW);
+  const int64_t nb = (int64_t)p.N * p.tz * p.ty * p.tx;
+  SEGMI_CHECK_ARG(nb < (1ll << 31), "convT3d: too many tiles");
+  dim3 grid((unsigned)nb, (unsigned)(p.Cout / (16 * NT)));
+  constexpr int lds = G::LDS_BYTES > 4 * 2 * NT * 16 * 4 ? G::LDS_BYTES : 4 * 2 * NT * 16 * 4;
+  hipLaunchKernelGGL((convt_fwd_mfma_kernel<T, CK, NT, TD, TH, TW>), grid, 256, lds, st, p);
+  SEGMI_LAUNCH_CHECK("convT3d_fwd(mfma)");
+  return SEGMI_OK;
+}
+
+template <typename T, int CK>
+static int launch_convt_nt(const ConvTParams& p, hipStream_t st) {
+  const bool wide = p.Wi > 8;
+  const int nt = p.Cout / 16;
+  if (nt % 2 == 0) {
+    if (wide) return launch_convt_cfg<T, CK, 2, 2, 2, 16>(p, st);
+    return launch_convt_cfg<T, CK, 2, 2, 4, 8>(p, st);
+  }
+  if (wide) return launch_convt_cfg<T, CK, 1, 2, 2, 16>(p, st);
+  return launch_convt_cfg<T, CK, 1, 2, 4, 8>(p, st);
+}
+
+template <typename T>
+static int launch_convt_mfma_t(ConvTParams p, hipStream_t st) {
+  constexpr int dt = sizeof(T) == 4 ? SEGMI_F32 : SEGMI_BF16;
+  const int ck = pick_ck(dt, p.Cin);
+  const PackGeom g = pack_geom(dt, p.Cin, p.Cout, 1);
+  int64_t off = 0;
+  for (int c = 0; c < 8; ++c) {
+    p.class_off[c] = off;
+    off += (int64_t)g.nchunks * ((ct_ntaps(c) * g.SPT + 3) / 4) * g.ntiles * 1024;
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (ck == 32) return launch_convt_nt<T, 32>(p, st);
+  }
+  return launch_convt_nt<T, 16>(p, st);
+}
+
+static inline int convt_mfma_rows(const segmi_act* in) {
+  const bool wide = in->w > 8;
+  const int td = 2, th = wide ? 2 : 4, tw = wide ? 16 : 8;
+  return in->n * cdiv(in->d, td) * cdiv(in->h, th) * cdiv(in->w, tw);
+}
+
+}  // namespace segmi

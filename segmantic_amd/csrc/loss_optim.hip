@@ -1,0 +1,356 @@
+// loss_optim.hip -- fused softmax + one-hot + Dice loss (forward / backward) and the
+// flat-arena optimisers (Adam, SGD, AdaBelief).  HBM-bound: logits are read once per pass in
+// 16-byte vectors along the class axis (NDHWC keeps the K classes of a voxel contiguous), the
+// softmax lives in registers, reductions are two-stage and deterministic.
+#include "common.h"
+
+namespace segmi {
+
+constexpr int kDiceVox = 8192;  // voxels per workgroup
+
+struct DiceParams {
+  const void* logits;
+  const float* labels;
+  float* partials;   // [n][chunks][3][k]
+  const float* coef; // [n][2][k]
+  void* dlogits;
+  int n, k, ld, ldd;
+  int64_t vox;       // voxels per batch item
+  int chunks;
+  float grad_scale;
+};
+
+template <typename T, int KMAX>
+__device__ __forceinline__ void load_logits(const T* p, int k, float (&v)[KMAX]) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (k % VEC == 0 && ((uintptr_t)p % 16) == 0) {
+#pragma unroll
+    for (int j = 0; j < KMAX; j += VEC) {
+      if (j < k) {
+        const frag_t f = *reinterpret_cast<const frag_t*>(p + j);
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (j + e < KMAX) v[j + e] = __uint_as_float(f[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (j + 2 * e < KMAX) v[j + 2 * e] = __uint_as_float(f[e] << 16);
+            if (j + 2 * e + 1 < KMAX) v[j + 2 * e + 1] = __uint_as_float(f[e] & 0xffff0000u);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) if (j < k) v[j] = Elem<T>::ld(p + j);
+  }
+}
+
+template <int KMAX>
+__device__ __forceinline__ void softmax_inplace(int k, float (&v)[KMAX]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) if (j < k) m = fmaxf(m, v[j]);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) if (j < k) { v[j] = expf(v[j] - m); s += v[j]; }
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) if (j < k) v[j] *= inv;
+}
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
+  __shared__ float red[4][3 * KMAX];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t v0 = (int64_t)chunk * kDiceVox;
+  const int64_t v1 = v0 + kDiceVox < p.vox ? v0 + kDiceVox : p.vox;
+  const T* lg = (const T*)p.logits + (int64_t)n * p.vox * p.ld;
+  const float* lb = p.labels + (int64_t)n * p.vox;
+  float si[KMAX], sp[KMAX], stt[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) si[j] = sp[j] = stt[j] = 0.f;
+  for (int64_t v = v0 + tid; v < v1; v += 256) {
+    float x[KMAX];
+    load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
+    softmax_inplace<KMAX>(p.k, x);
+    const int lab = (int)lb[v];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < p.k) {
+        sp[j] += x[j];
+        if (j == lab) { si[j] += x[j]; stt[j] += 1.f; }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < p.k) {
+      const float a = wave_sum(si[j]), b = wave_sum(sp[j]), c = wave_sum(stt[j]);
+      if (lane == 0) { red[wave][j] = a; red[wave][KMAX + j] = b; red[wave][2 * KMAX + j] = c; }
+    }
+  }
+  __syncthreads();
+  if (tid < 3 * p.k) {
+    const int which = tid / p.k, j = tid % p.k;
+    const float s = red[0][which * KMAX + j] + red[1][which * KMAX + j] +
+                    red[2][which * KMAX + j] + red[3][which * KMAX + j];
+    p.partials[(((int64_t)n * p.chunks + chunk) * 3 + which) * p.k + j] = s;
+  }
+}
+
+// one block: per (n,k) sums in f64, loss + backward coefficients
+__global__ __launch_bounds__(256) void dice_finalize_kernel(const float* __restrict__ partials,
+                                                            int n, int k, int chunks,
+                                                            float smooth_nr, float smooth_dr,
+                                                            float* coef, float* loss) {
+  __shared__ double fsum[256];
+  const int tid = threadIdx.x;
+  double local = 0.0;
+  const double nk = (double)n * k;
+  for (int o = tid; o < n * k; o += 256) {
+    const int b = o / k, j = o % k;
+    double I = 0.0, P = 0.0, Tt = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+      const float* q = partials + (((int64_t)b * chunks + c) * 3) * k + j;
+      I += (double)q[0]; P += (double)q[k]; Tt += (double)q[2 * k];
+    }
+    // f32 arithmetic as the reference does on the reduced sums
+    const float If = (float)I, Df = (float)Tt + (float)P;
+    const float f = 1.0f - (2.0f * If + smooth_nr) / (Df + smooth_dr);
+    local += (double)f;
+    const double den = (double)Df + (double)smooth_dr;
+    coef[((int64_t)b * 2 + 0) * k + j] = (float)(-2.0 / den / nk);
+    coef[((int64_t)b * 2 + 1) * k + j] = (float)((2.0 * (double)If + (double)smooth_nr) / (den * den) / nk);
+  }
+  fsum[tid] = local;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += fsum[i];
+    *loss = (float)(t / nk);
+  }
+}
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
+  __shared__ float cf[2 * KMAX];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < 2 * p.k) cf[(tid / p.k) * KMAX + tid % p.k] = p.coef[(int64_t)n * 2 * p.k + tid];
+  __syncthreads();
+  const int64_t v0 = (int64_t)chunk * kDiceVox;
+  const int64_t v1 = v0 + kDiceVox < p.vox ? v0 + kDiceVox : p.vox;
+  const T* lg = (const T*)p.logits + (int64_t)n * p.vox * p.ld;
+  T* dl = (T*)p.dlogits + (int64_t)n * p.vox * p.ldd;
+  const float* lb = p.labels + (int64_t)n * p.vox;
+  for (int64_t v = v0 + tid; v < v1; v += 256) {
+    float x[KMAX];
+    load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
+    softmax_inplace<KMAX>(p.k, x);
+    const int lab = (int)lb[v];
+    float dot = 0.f;
+    float dp[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < p.k) {
+        dp[j] = cf[KMAX + j] + (j == lab ? cf[j] : 0.f);
+        dot = fmaf(x[j], dp[j], dot);
+      }
+    }
+    T* o = dl + v * p.ldd;
+    if (p.k % 4 == 0 && ((uintptr_t)o % (4 * sizeof(T))) == 0) {
+#pragma unroll
+      for (int j = 0; j < KMAX; j += 4) {
+        if (j < p.k) {
+          f32x4 g4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g4[e] = (j + e < KMAX) ? p.grad_scale * x[j + e] * (dp[j + e] - dot) : 0.f;
+          store4<T>(o + j, g4);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+        if (j < p.k) Elem<T>::st(o + j, p.grad_scale * x[j] * (dp[j] - dot));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- optimisers
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ vmax, int64_t n, float beta1, float beta2,
+                            float eps, float wd, float step_size, float bc2_sqrt,
+                            float grad_scale) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * grad_scale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = m[i];
+    mi = mi + (1.f - beta1) * (gi - mi);          // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = v[i] * beta2;
+    vi = fmaf((1.f - beta2) * gi, gi, vi);        // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    float vv = vi;
+    if (vmax) { vv = fmaxf(vmax[i], vi); vmax[i] = vv; }
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                           float* __restrict__ buf, int64_t n, float lr, float momentum,
+                           float wd, int first, float grad_scale) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * grad_scale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    if (momentum != 0.f) {
+      const float b = first ? gi : fmaf(buf[i], momentum, gi);
+      buf[i] = b;
+      gi = b;
+    }
+    p[i] = pi - lr * gi;
+  }
+}
+
+__global__ void adabelief_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                 float* __restrict__ m, float* __restrict__ s, int64_t n,
+                                 float lr, float beta1, float beta2, float eps, float wd,
+                                 int decouple, float step_size, float bc2_sqrt,
+                                 float grad_scale) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * grad_scale;
+    float pi = p[i];
+    if (wd != 0.f) {
+      if (decouple) pi *= (1.f - lr * wd);
+      else gi = fmaf(wd, pi, gi);
+    }
+    const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+    const float r = gi - mi;
+    float si = s[i] * beta2 + (1.f - beta2) * r * r;
+    si += eps;  // exp_avg_var.add_(eps) is in place in adabelief_pytorch
+    m[i] = mi;
+    s[i] = si;
+    const float denom = sqrtf(si) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+static inline int opt_blocks(int64_t n) {
+  const int64_t b = cdiv64(n, 256);
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+template <typename T>
+static int dice_dispatch(bool fwd, const DiceParams& p, hipStream_t st) {
+  dim3 grid(p.chunks, p.n);
+#define DICE_K(KM)                                                                       \
+  do {                                                                                   \
+    if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM>), grid, 256, 0, st, p);          \
+    else hipLaunchKernelGGL((dice_bwd_kernel<T, KM>), grid, 256, 0, st, p);              \
+  } while (0)
+  if (p.k <= 4) DICE_K(4);
+  else if (p.k <= 16) DICE_K(16);
+  else if (p.k <= 32) DICE_K(32);
+  else if (p.k <= 64) DICE_K(64);
+  else SEGMI_UNSUPPORTED("softmax_dice: at most 64 classes (got %d)", p.k);
+#undef DICE_K
+  SEGMI_LAUNCH_CHECK("softmax_dice");
+  return SEGMI_OK;
+}
+
+}  // namespace segmi
+
+using namespace segmi;
+
+extern "C" {
+
+int segmi_dice_chunks(const segmi_act* logits) {
+  if (!logits) return 0;
+  return (int)cdiv64((int64_t)logits->d * logits->h * logits->w, kDiceVox);
+}
+
+int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labels,
+                           float* partials, float* coef, float* loss, float smooth_nr,
+                           float smooth_dr, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "softmax_dice_fwd: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(logits) && labels && partials && coef && loss, "softmax_dice_fwd: bad arguments");
+  DiceParams p{};
+  p.logits = logits->data; p.labels = labels; p.partials = partials;
+  p.n = logits->n; p.k = logits->c; p.ld = logits->ld;
+  p.vox = (int64_t)logits->d * logits->h * logits->w;
+  p.chunks = segmi_dice_chunks(logits);
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = dtype == SEGMI_F32 ? dice_dispatch<float>(true, p, st)
+                                    : dice_dispatch<bf16_t>(true, p, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dice_finalize_kernel, 1, 256, 0, st, (const float*)partials, p.n, p.k,
+                     p.chunks, smooth_nr, smooth_dr, coef, loss);
+  SEGMI_LAUNCH_CHECK("softmax_dice_fwd(finalize)");
+  return SEGMI_OK;
+}
+
+int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labels,
+                           const float* coef, float grad_scale, const segmi_act* dlogits,
+                           void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "softmax_dice_bwd: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(logits) && act_ok(dlogits) && labels && coef &&
+                      logits->n == dlogits->n && logits->d == dlogits->d &&
+                      logits->h == dlogits->h && logits->w == dlogits->w &&
+                      logits->c == dlogits->c, "softmax_dice_bwd: bad arguments");
+  DiceParams p{};
+  p.logits = logits->data; p.labels = labels; p.coef = coef; p.dlogits = dlogits->data;
+  p.n = logits->n; p.k = logits->c; p.ld = logits->ld; p.ldd = dlogits->ld;
+  p.vox = (int64_t)logits->d * logits->h * logits->w;
+  p.chunks = segmi_dice_chunks(logits);
+  p.grad_scale = grad_scale;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == SEGMI_F32 ? dice_dispatch<float>(false, p, st)
+                            : dice_dispatch<bf16_t>(false, p, st);
+}
+
+int segmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    float* max_exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int64_t step, float grad_scale,
+                    void* stream) {
+  SEGMI_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "adam: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, opt_blocks(n), 256, 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, max_exp_avg_sq, n, beta1, beta2, eps, weight_decay,
+                     step_size, bc2_sqrt, grad_scale);
+  SEGMI_LAUNCH_CHECK("adam");
+  return SEGMI_OK;
+}
+
+int segmi_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                   float momentum, float weight_decay, int first_step, float grad_scale,
+                   void* stream) {
+  SEGMI_CHECK_ARG(param && grad && n > 0 && (momentum == 0.f || momentum_buf), "sgd: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, opt_blocks(n), 256, 0, (hipStream_t)stream, param, grad,
+                     momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale);
+  SEGMI_LAUNCH_CHECK("sgd");
+  return SEGMI_OK;
+}
+
+int segmi_adabelief_step(float* param, const float* grad, float* exp_avg, float* exp_avg_var,
+                         int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int weight_decouple, int64_t step,
+                         float grad_scale, void* stream) {
+  SEGMI_CHECK_ARG(param && grad && exp_avg && exp_avg_var && n > 0 && step > 0, "adabelief: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adabelief_kernel, opt_blocks(n), 256, 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_var, n, lr, beta1, beta2, eps, weight_decay,
+                     weight_decouple, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+  SEGMI_LAUNCH_CHECK("adabelief");
+  return SEGMI_OK;
+}
+
+}  // extern "C"

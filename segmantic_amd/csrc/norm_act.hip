@@ -1,0 +1,567 @@
+// norm_act.hip -- BatchNorm3d (training statistics) + PReLU forward/backward and elementwise
+// helpers on NDHWC views.  All kernels are HBM-bound: 16-byte vector access per lane along the
+// channel axis, per-channel parameters cached in LDS, deterministic two-stage reductions
+// (per-workgroup partials in f32, final reduce in f64) -- no float atomics anywhere.
+#include "common.h"
+
+namespace segmi {
+
+constexpr int kStatVox = 4096;  // voxels per workgroup in the reduction kernels
+
+int bn_stats_rows_for(const segmi_act* x) { return (int)cdiv64(act_voxels(x), kStatVox); }
+
+template <typename T, int VEC>
+__device__ __forceinline__ void loadv(const T* p, float (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    v[0] = Elem<T>::ld(p);
+  } else if constexpr (sizeof(T) == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  } else {
+    const f32x4 a = load4<T>(p);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void storev(T* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    Elem<T>::st(p, v[0]);
+  } else {
+    store4<T>(p, f32x4{v[0], v[1], v[2], v[3]});
+  }
+}
+
+struct EwParams {
+  const void* x; const void* y; const void* r; void* o;
+  int64_t nvox;
+  int c, ldx, ldy, ldr, ldo;
+  const float* p0; const float* p1; const float* p2; const float* p3; const float* alpha;
+  const float* coef;
+  float* out_partials;
+};
+
+// ---------------------------------------------------------------- statistics
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(EwParams p) {
+  __shared__ float red[256 * 2 * VEC];
+  const int cg = p.c / VEC;              // channel groups per voxel
+  const int vpp = 256 / cg > 0 ? 256 / cg : 1;  // voxels per pass
+  const int tid = threadIdx.x;
+  const int my_cg = tid % cg, my_v = tid / cg;
+  const int64_t v0 = (int64_t)blockIdx.x * kStatVox;
+  const int64_t v1 = v0 + kStatVox < p.nvox ? v0 + kStatVox : p.nvox;
+  const T* x = (const T*)p.x;
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) s[k] = q[k] = 0.f;
+  if (my_v < vpp && cg <= 256) {
+    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
+      float a[VEC];
+      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { s[k] += a[k]; q[k] = fmaf(a[k], a[k], q[k]); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) { red[tid * 2 * VEC + k] = s[k]; red[tid * 2 * VEC + VEC + k] = q[k]; }
+  __syncthreads();
+  // thread (which, channel) sums the voxel lanes in fixed order
+  for (int o = tid; o < 2 * p.c; o += 256) {
+    const int which = o / p.c, ch = o % p.c;
+    const int g = ch / VEC, k = ch % VEC;
+    float acc = 0.f;
+    for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 2 * VEC + which * VEC + k];
+    p.out_partials[((int64_t)blockIdx.x * 2 + which) * p.c + ch] = acc;
+  }
+}
+
+// wide-channel fallback (c/VEC > 256): one thread per channel loop
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_wide_kernel(EwParams p) {
+  const int64_t v0 = (int64_t)blockIdx.x * kStatVox;
+  const int64_t v1 = v0 + kStatVox < p.nvox ? v0 + kStatVox : p.nvox;
+  const T* x = (const T*)p.x;
+  for (int ch = threadIdx.x; ch < p.c; ch += 256) {
+    float s = 0.f, q = 0.f;
+    for (int64_t v = v0; v < v1; ++v) {
+      const float a = Elem<T>::ld(x + v * p.ldx + ch);
+      s += a; q = fmaf(a, a, q);
+    }
+    p.out_partials[((int64_t)blockIdx.x * 2 + 0) * p.c + ch] = s;
+    p.out_partials[((int64_t)blockIdx.x * 2 + 1) * p.c + ch] = q;
+  }
+}
+
+static inline bool vec4_ok(const segmi_act* a, int dtype) {
+  const int es = dtype_size(dtype);
+  return a->c % 4 == 0 && a->ld % 4 == 0 && ((uintptr_t)a->data % (4 * es)) == 0;
+}
+
+int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st) {
+  EwParams p{};
+  p.x = x->data; p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld; p.out_partials = partials;
+  const int rows = bn_stats_rows_for(x);
+  const bool v4 = vec4_ok(x, dtype) && x->c / 4 <= 256;
+  if (v4) {
+    if (dtype == SEGMI_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), rows, 256, 0, st, p);
+    else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 4>), rows, 256, 0, st, p);
+  } else if (x->c <= 256) {
+    if (dtype == SEGMI_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 1>), rows, 256, 0, st, p);
+    else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), rows, 256, 0, st, p);
+  } else {
+    if (dtype == SEGMI_F32) hipLaunchKernelGGL(bn_stats_wide_kernel<float>, rows, 256, 0, st, p);
+    else hipLaunchKernelGGL(bn_stats_wide_kernel<bf16_t>, rows, 256, 0, st, p);
+  }
+  SEGMI_LAUNCH_CHECK("bn_stats");
+  return SEGMI_OK;
+}
+
+// partials [rows][2][c] -> per-channel statistics (f64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partials, int rows, int c, double count, const float* gamma,
+    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* mean, float* invstd, float* scale, float* shift) {
+  __shared__ double red[2][256];
+  const int cp = c < 256 ? c : 256;
+  const int parts = 256 / cp;
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < c; c0 += cp) {
+    const int ch = c0 + tid % cp, part = tid / cp;
+    double s = 0.0, q = 0.0;
+    if (part < parts && ch < c) {
+      for (int r = part; r < rows; r += parts) {
+        s += (double)partials[((int64_t)r * 2 + 0) * c + ch];
+        q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
+      }
+    }
+    red[0][tid] = s; red[1][tid] = q;
+    __syncthreads();
+    if (tid < cp && c0 + tid < c) {
+      double ss = 0.0, qq = 0.0;
+      for (int pi = 0; pi < parts; ++pi) { ss += red[0][pi * cp + tid]; qq += red[1][pi * cp + tid]; }
+      const double m = ss / count;
+      double var = qq / count - m * m;
+      if (var < 0.0) var = 0.0;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const int cc = c0 + tid;
+      mean[cc] = (float)m;
+      invstd[cc] = is;
+      const float sc = (gamma ? gamma[cc] : 1.f) * is;
+      scale[cc] = sc;
+      shift[cc] = (beta ? beta[cc] : 0.f) - (float)m * sc;
+      if (running_mean) running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * (float)m;
+      if (running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * (float)unb;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_eval_affine_kernel(int c, const float* gamma, const float* beta,
+                                      const float* rm, const float* rv, float eps, float* scale,
+                                      float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c) {
+    const float is = 1.f / sqrtf(rv[i] + eps);
+    const float sc = (gamma ? gamma[i] : 1.f) * is;
+    scale[i] = sc;
+    shift[i] = (beta ? beta[i] : 0.f) - rm[i] * sc;
+  }
+}
+
+// ---------------------------------------------------------------- forward apply
+// y = prelu(x*scale + shift) + r ; scale/shift nullable (identity), alpha nullable, r nullable
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(EwParams p) {
+  extern __shared__ float prm[];  // [2][c]
+  for (int i = threadIdx.x; i < p.c; i += 256) {
+    prm[i] = p.p0 ? p.p0[i] : 1.f;
+    prm[p.c + i] = p.p1 ? p.p1[i] : 0.f;
+  }
+  __syncthreads();
+  const bool has_alpha = p.alpha != nullptr;
+  const float alpha = has_alpha ? *p.alpha : 0.f;
+  const int cg = p.c / VEC;
+  const int64_t total = p.nvox * cg;
+  const T* x = (const T*)p.x;
+  const T* r = (const T*)p.r;
+  T* o = (T*)p.o;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = e / cg;
+    const int ch = (int)(e - v * cg) * VEC;
+    float a[VEC];
+    loadv<T, VEC>(x + v * p.ldx + ch, a);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float z = fmaf(a[k], prm[ch + k], prm[p.c + ch + k]);
+      if (has_alpha) z = z > 0.f ? z : alpha * z;
+      a[k] = z;
+    }
+    if (r) {
+      float b[VEC];
+      loadv<T, VEC>(r + v * p.ldr + ch, b);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) a[k] += b[k];
+    }
+    storev<T, VEC>(o + v * p.ldo + ch, a);
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// p0=mean p1=invstd p2=gamma p3=beta ; x = forward input (raw conv output), y = dy
+// partials [rows][3][c]: sum dz, sum dz*xhat, sum dy*z*[z<=0]
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
+  __shared__ float red[256 * 3 * VEC];
+  const int cg = p.c / VEC;
+  const int vpp = 256 / cg > 0 ? 256 / cg : 1;
+  const int tid = threadIdx.x;
+  const int my_cg = tid % cg, my_v = tid / cg;
+  const int64_t v0 = (int64_t)blockIdx.x * kStatVox;
+  const int64_t v1 = v0 + kStatVox < p.nvox ? v0 + kStatVox : p.nvox;
+  const T* x = (const T*)p.x;
+  const T* dy = (const T*)p.y;
+  const bool has_alpha = p.alpha != nullptr;
+  const float alpha = has_alpha ? *p.alpha : 1.f;
+  float s0[VEC], s1[VEC], s2[VEC], mean[VEC], istd[VEC], gam[VEC], bet[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    s0[k] = s1[k] = s2[k] = 0.f;
+    const int ch = my_cg * VEC + k;
+    const bool ok = my_v < vpp;
+    mean[k] = ok ? p.p0[ch] : 0.f;
+    istd[k] = ok ? p.p1[ch] : 0.f;
+    gam[k] = ok ? (p.p2 ? p.p2[ch] : 1.f) : 0.f;
+    bet[k] = ok ? (p.p3 ? p.p3[ch] : 0.f) : 0.f;
+  }
+  if (my_v < vpp) {
+    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
+      float a[VEC], d[VEC];
+      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
+      loadv<T, VEC>(dy + v * p.ldy + my_cg * VEC, d);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float xh = (a[k] - mean[k]) * istd[k];
+        const float z = fmaf(xh, gam[k], bet[k]);
+        float dz = d[k];
+        if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[k], z, s2[k]); dz = alpha * d[k]; }
+        s0[k] += dz;
+        s1[k] = fmaf(dz, xh, s1[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    red[tid * 3 * VEC + k] = s0[k];
+    red[tid * 3 * VEC + VEC + k] = s1[k];
+    red[tid * 3 * VEC + 2 * VEC + k] = s2[k];
+  }
+  __syncthreads();
+  for (int o = tid; o < 3 * p.c; o += 256) {
+    const int which = o / p.c, ch = o % p.c;
+    const int g = ch / VEC, k = ch % VEC;
+    float acc = 0.f;
+    for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 3 * VEC + which * VEC + k];
+    p.out_partials[((int64_t)blockIdx.x * 3 + which) * p.c + ch] = acc;
+  }
+}
+
+// partials -> dgamma, dbeta, dalpha(sum over channels), coef[2][c] = {mean dz, mean dz*xhat}
+__global__ __launch_bounds__(256) void bn_act_bwd_finalize_kernel(
+    const float* __restrict__ partials, int rows, int c, double count, float* dgamma,
+    float* dbeta, float* dalpha, float* coef) {
+  __shared__ double red[3][256];
+  __shared__ double asum[256];
+  const int cp = c < 256 ? c : 256;
+  const int parts = 256 / cp;
+  const int tid = threadIdx.x;
+  double alpha_acc = 0.0;
+  for (int c0 = 0; c0 < c; c0 += cp) {
+    const int ch = c0 + tid % cp, part = tid / cp;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (part < parts && ch < c) {
+      for (int r = part; r < rows; r += parts) {
+        s0 += (double)partials[((int64_t)r * 3 + 0) * c + ch];
+        s1 += (double)partials[((int64_t)r * 3 + 1) * c + ch];
+        s2 += (double)partials[((int64_t)r * 3 + 2) * c + ch];
+      }
+    }
+    red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
+    __syncthreads();
+    if (tid < cp && c0 + tid < c) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int pi = 0; pi < parts; ++pi) {
+        a0 += red[0][pi * cp + tid]; a1 += red[1][pi * cp + tid]; a2 += red[2][pi * cp + tid];
+      }
+      const int cc = c0 + tid;
+      if (dbeta) dbeta[cc] = (float)a0;
+      if (dgamma) dgamma[cc] = (float)a1;
+      coef[cc] = (float)(a0 / count);
+      coef[c + cc] = (float)(a1 / count);
+      alpha_acc += a2;
+    }
+    __syncthreads();
+  }
+  asum[tid] = alpha_acc;
+  __syncthreads();
+  if (tid == 0 && dalpha) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += asum[i];
+    *dalpha = (float)t;
+  }
+}
+
+// dx = gamma*invstd*(dz - c0 - xhat*c1)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(EwParams p) {
+  extern __shared__ float prm[];  // [6][c]: mean invstd gamma beta c0 c1
+  for (int i = threadIdx.x; i < p.c; i += 256) {
+    prm[i] = p.p0[i];
+    prm[p.c + i] = p.p1[i];
+    prm[2 * p.c + i] = p.p2 ? p.p2[i] : 1.f;
+    prm[3 * p.c + i] = p.p3 ? p.p3[i] : 0.f;
+    prm[4 * p.c + i] = p.coef[i];
+    prm[5 * p.c + i] = p.coef[p.c + i];
+  }
+  __syncthreads();
+  const bool has_alpha = p.alpha != nullptr;
+  const float alpha = has_alpha ? *p.alpha : 1.f;
+  const int cg = p.c / VEC;
+  const int64_t total = p.nvox * cg;
+  const T* x = (const T*)p.x;
+  const T* dy = (const T*)p.y;
+  T* o = (T*)p.o;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = e / cg;
+    const int ch = (int)(e - v * cg) * VEC;
+    float a[VEC], d[VEC];
+    loadv<T, VEC>(x + v * p.ldx + ch, a);
+    loadv<T, VEC>(dy + v * p.ldy + ch, d);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float is = prm[p.c + ch + k], gm = prm[2 * p.c + ch + k];
+      const float xh = (a[k] - prm[ch + k]) * is;
+      const float z = fmaf(xh, gm, prm[3 * p.c + ch + k]);
+      float dz = d[k];
+      if (has_alpha && !(z > 0.f)) dz = alpha * d[k];
+      a[k] = gm * is * (dz - prm[4 * p.c + ch + k] - xh * prm[5 * p.c + ch + k]);
+    }
+    storev<T, VEC>(o + v * p.ldo + ch, a);
+  }
+}
+
+// ---------------------------------------------------------------- misc elementwise
+template <typename TS, typename TD>
+__global__ void cast_copy_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t nvox,
+                                 int c, int lds_, int ldd) {
+  const int64_t total = nvox * c;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = e / c;
+    const int ch = (int)(e - v * c);
+    Elem<TD>::st(d + v * ldd + ch, Elem<TS>::ld(s + v * lds_ + ch));
+  }
+}
+
+// src NCDHW f32 [n][c][vox] <-> dst NDHWC
+template <typename T>
+__global__ void nchw_to_ndhwc_kernel(const float* __restrict__ s, T* __restrict__ d, int n,
+                                     int c, int64_t vox, int ld) {
+  const int64_t total = (int64_t)n * vox * c;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    const int64_t v = e / c;           // n*vox + voxel
+    const int64_t b = v / vox, vv = v - b * vox;
+    Elem<T>::st(d + v * ld + ch, s[(b * c + ch) * vox + vv]);
+  }
+}
+template <typename T>
+__global__ void ndhwc_to_nchw_kernel(const T* __restrict__ s, float* __restrict__ d, int n,
+                                     int c, int64_t vox, int ld) {
+  const int64_t total = (int64_t)n * vox * c;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t vv = e % vox;        // voxel fastest on the write side
+    const int64_t t = e / vox;
+    const int ch = (int)(t % c);
+    const int64_t b = t / c;
+    d[e] = Elem<T>::ld(s + (b * vox + vv) * ld + ch);
+  }
+}
+
+static inline int ew_blocks(int64_t total) {
+  const int64_t b = cdiv64(total, 256);
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+static inline bool same_shape(const segmi_act* a, const segmi_act* b) {
+  return a->n == b->n && a->d == b->d && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+
+}  // namespace segmi
+
+using namespace segmi;
+
+#define DISPATCH_TV(KERN, dtype, v4, grid, lds, st, p)                                        \
+  do {                                                                                        \
+    if (dtype == SEGMI_F32) {                                                                 \
+      if (v4) hipLaunchKernelGGL((KERN<float, 4>), grid, 256, lds, st, p);                    \
+      else hipLaunchKernelGGL((KERN<float, 1>), grid, 256, lds, st, p);                       \
+    } else {                                                                                  \
+      if (v4) hipLaunchKernelGGL((KERN<bf16_t, 4>), grid, 256, lds, st, p);                   \
+      else hipLaunchKernelGGL((KERN<bf16_t, 1>), grid, 256, lds, st, p);                      \
+    }                                                                                         \
+  } while (0)
+
+extern "C" {
+
+int segmi_bn_stats_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) : 0; }
+
+int segmi_bn_stats(int dtype, const segmi_act* x, float* stats_partials, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_stats: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(x) && stats_partials, "bn_stats: bad arguments");
+  return bn_stats_launch(dtype, x, stats_partials, (hipStream_t)stream);
+}
+
+int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count,
+                      const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, float* mean,
+                      float* invstd, float* scale, float* shift, void* stream) {
+  SEGMI_CHECK_ARG(stats_partials && rows > 0 && c > 0 && count > 0 && mean && invstd && scale &&
+                      shift, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, 1, 256, 0, (hipStream_t)stream, stats_partials, rows, c,
+                     count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                     scale, shift);
+  SEGMI_LAUNCH_CHECK("bn_finalize");
+  return SEGMI_OK;
+}
+
+int segmi_bn_eval_affine(int c, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps,
+                         float* scale, float* shift, void* stream) {
+  SEGMI_CHECK_ARG(c > 0 && running_mean && running_var && scale && shift,
+                  "bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, cdiv(c, 256), 256, 0, (hipStream_t)stream, c, gamma,
+                     beta, running_mean, running_var, eps, scale, shift);
+  SEGMI_LAUNCH_CHECK("bn_eval_affine");
+  return SEGMI_OK;
+}
+
+int segmi_bn_act_fwd(int dtype, const segmi_act* x, const segmi_act* y, const float* scale,
+                     const float* shift, const float* prelu_alpha, const segmi_act* residual,
+                     void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_fwd: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(x) && act_ok(y) && same_shape(x, y), "bn_act_fwd: shape mismatch");
+  if (residual) SEGMI_CHECK_ARG(act_ok(residual) && same_shape(x, residual), "bn_act_fwd: residual shape");
+  EwParams p{};
+  p.x = x->data; p.o = y->data; p.r = residual ? residual->data : nullptr;
+  p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld; p.ldo = y->ld;
+  p.ldr = residual ? residual->ld : 0;
+  p.p0 = scale; p.p1 = shift; p.alpha = prelu_alpha;
+  const bool v4 = vec4_ok(x, dtype) && vec4_ok(y, dtype) && (!residual || vec4_ok(residual, dtype));
+  const int grid = ew_blocks(p.nvox * (x->c / (v4 ? 4 : 1)));
+  DISPATCH_TV(bn_act_fwd_kernel, dtype, v4, grid, 2 * x->c * sizeof(float), (hipStream_t)stream, p);
+  SEGMI_LAUNCH_CHECK("bn_act_fwd");
+  return SEGMI_OK;
+}
+
+int segmi_add(int dtype, const segmi_act* a, const segmi_act* b, const segmi_act* out,
+              void* stream) {
+  return segmi_bn_act_fwd(dtype, a, out, nullptr, nullptr, nullptr, b, stream);
+}
+
+int segmi_bn_act_bwd_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) : 0; }
+
+int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
+                            const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* prelu_alpha, float* red_partials,
+                            void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_bwd_reduce: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(dy) && act_ok(x) && same_shape(x, dy) && mean && invstd && red_partials,
+                  "bn_act_bwd_reduce: bad arguments");
+  SEGMI_CHECK_ARG(x->c <= 256, "bn_act_bwd_reduce: at most 256 channels per call");
+  EwParams p{};
+  p.x = x->data; p.y = dy->data; p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld;
+  p.ldy = dy->ld; p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha;
+  p.out_partials = red_partials;
+  const bool v4 = vec4_ok(x, dtype) && vec4_ok(dy, dtype);
+  const int rows = bn_stats_rows_for(x);
+  DISPATCH_TV(bn_act_bwd_reduce_kernel, dtype, v4, rows, 0, (hipStream_t)stream, p);
+  SEGMI_LAUNCH_CHECK("bn_act_bwd_reduce");
+  return SEGMI_OK;
+}
+
+int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double count,
+                              const float* gamma, const float* invstd, float* dgamma,
+                              float* dbeta, float* dalpha, float* coef, void* stream) {
+  (void)gamma; (void)invstd;
+  SEGMI_CHECK_ARG(red_partials && rows > 0 && c > 0 && count > 0 && coef,
+                  "bn_act_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, 1, 256, 0, (hipStream_t)stream, red_partials,
+                     rows, c, count, dgamma, dbeta, dalpha, coef);
+  SEGMI_LAUNCH_CHECK("bn_act_bwd_finalize");
+  return SEGMI_OK;
+}
+
+int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
+                           const segmi_act* dx, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, const float* prelu_alpha,
+                           const float* coef, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_bwd_apply: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(dy) && act_ok(x) && act_ok(dx) && same_shape(x, dy) && same_shape(x, dx) &&
+                      mean && invstd && coef, "bn_act_bwd_apply: bad arguments");
+  EwParams p{};
+  p.x = x->data; p.y = dy->data; p.o = dx->data; p.nvox = act_voxels(x); p.c = x->c;
+  p.ldx = x->ld; p.ldy = dy->ld; p.ldo = dx->ld;
+  p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha; p.coef = coef;
+  const bool v4 = vec4_ok(x, dtype) && vec4_ok(dy, dtype) && vec4_ok(dx, dtype);
+  const int grid = ew_blocks(p.nvox * (x->c / (v4 ? 4 : 1)));
+  DISPATCH_TV(bn_act_bwd_apply_kernel, dtype, v4, grid, 6 * x->c * sizeof(float), (hipStream_t)stream, p);
+  SEGMI_LAUNCH_CHECK("bn_act_bwd_apply");
+  return SEGMI_OK;
+}
+
+int segmi_cast_copy(int src_dtype, const segmi_act* src, int dst_dtype, const segmi_act* dst,
+                    void* stream) {
+  SEGMI_CHECK_ARG(act_ok(src) && act_ok(dst) && same_shape(src, dst), "cast_copy: shape mismatch");
+  const int64_t nvox = act_voxels(src);
+  const int grid = ew_blocks(nvox * src->c);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == SEGMI_F32 && dst_dtype == SEGMI_F32)
+    hipLaunchKernelGGL((cast_copy_kernel<float, float>), grid, 256, 0, st, (const float*)src->data, (float*)dst->data, nvox, src->c, src->ld, dst->ld);
+  else if (src_dtype == SEGMI_F32 && dst_dtype == SEGMI_BF16)
+    hipLaunchKernelGGL((cast_copy_kernel<float, bf16_t>), grid, 256, 0, st, (const float*)src->data, (bf16_t*)dst->data, nvox, src->c, src->ld, dst->ld);
+  else if (src_dtype == SEGMI_BF16 && dst_dtype == SEGMI_F32)
+    hipLaunchKernelGGL((cast_copy_kernel<bf16_t, float>), grid, 256, 0, st, (const bf16_t*)src->data, (float*)dst->data, nvox, src->c, src->ld, dst->ld);
+  else if (src_dtype == SEGMI_BF16 && dst_dtype == SEGMI_BF16)
+    hipLaunchKernelGGL((cast_copy_kernel<bf16_t, bf16_t>), grid, 256, 0, st, (const bf16_t*)src->data, (bf16_t*)dst->data, nvox, src->c, src->ld, dst->ld);
+  else SEGMI_CHECK_ARG(false, "cast_copy: bad dtypes");
+  SEGMI_LAUNCH_CHECK("cast_copy");
+  return SEGMI_OK;
+}
+
+int segmi_nchw_to_ndhwc(const float* src, int dst_dtype, const segmi_act* dst, void* stream) {
+  SEGMI_CHECK_ARG(src && act_ok(dst), "nchw_to_ndhwc: bad arguments");
+  const int64_t vox = (int64_t)dst->d * dst->h * dst->w;
+  const int grid = ew_blocks((int64_t)dst->n * vox * dst->c);
+  if (dst_dtype == SEGMI_F32)
+    hipLaunchKernelGGL(nchw_to_ndhwc_kernel<float>, grid, 256, 0, (hipStream_t)stream, src, (float*)dst->data, dst->n, dst->c, vox, dst->ld);
+  else
+    hipLaunchKernelGGL(nchw_to_ndhwc_kernel<bf16_t>, grid, 256, 0, (hipStream_t)stream, src, (bf16_t*)dst->data, dst->n, dst->c, vox, dst->ld);
+  SEGMI_LAUNCH_CHECK("nchw_to_ndhwc");
+  return SEGMI_OK;
+}
+
+int segmi_ndhwc_to_nchw(int src_dtype, const segmi_act* src, float* dst, void* stream) {
+  SEGMI_CHECK_ARG(dst && act_ok(src), "ndhwc_to_nchw: bad arguments");
+  const int64_t vox = (int64_t)src->d * src->h * src->w;
+  const int grid = ew_blocks((int64_t)src->n * vox * src->c);
+  if (src_dtype == SEGMI_F32)
+    hipLaunchKernelGGL(ndhwc_to_nchw_kernel<float>, grid, 256, 0, (hipStream_t)stream, (const float*)src->data, dst, src->n, src->c, vox, src->ld);
+  else
+    hipLaunchKernelGGL(ndhwc_to_nchw_kernel<bf16_t>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)src->data, dst, src->n, src->c, vox, src->ld);
+  SEGMI_LAUNCH_CHECK("ndhwc_to_nchw");
+  return SEGMI_OK;
+}
+
+}  // extern "C"

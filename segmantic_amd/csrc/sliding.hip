@@ -1,0 +1,283 @@
+// sliding.hip -- sliding-window inference data movement (gather / ordered blend / finalise),
+// channel argmax, label overlap counts and the on-device patch cropper.  All HBM-bound.
+#include "common.h"
+
+namespace segmi {
+
+constexpr int kMaxWin = 16;
+
+struct WinList {
+  int n;
+  int z[kMaxWin], y[kMaxWin], x[kMaxWin];
+};
+
+template <typename TS, typename TD>
+__global__ void sw_gather_kernel(const TS* __restrict__ img, TD* __restrict__ win, WinList wl,
+                                 int D, int H, int W, int C, int ldi, int rd, int rh, int rw,
+                                 int ldw) {
+  const int64_t per = (int64_t)rd * rh * rw * C;
+  const int64_t total = per * wl.n;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % C;
+    int64_t t = e / C;
+    const int x = t % rw; t /= rw;
+    const int y = t % rh; t /= rh;
+    const int z = t % rd;
+    const int w = t / rd;
+    const int gz = wl.z[w] + z, gy = wl.y[w] + y, gx = wl.x[w] + x;
+    float v = 0.f;
+    if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+      v = Elem<TS>::ld(img + (((int64_t)gz * H + gy) * W + gx) * ldi + c);
+    Elem<TD>::st(win + ((((int64_t)w * rd + z) * rh + y) * rw + x) * ldw + c, v);
+  }
+}
+
+// one thread per (voxel of the windows' bounding box, channel); windows applied IN ORDER so the
+// f32 accumulation order equals the reference's sequential `out[slice] += w * pred`.
+template <typename T>
+__global__ void sw_scatter_kernel(const T* __restrict__ pred, WinList wl, const float* __restrict__ imp,
+                                  float* __restrict__ acc, float* __restrict__ cnt, int D, int H,
+                                  int W, int K, int lda, int rd, int rh, int rw, int ldp, int bz0,
+                                  int by0, int bx0, int bd, int bh, int bw) {
+  const int64_t total = (int64_t)bd * bh * bw * K;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int k = e % K;
+    int64_t t = e / K;
+    const int x = bx0 + t % bw; t /= bw;
+    const int y = by0 + t % bh; t /= bh;
+    const int z = bz0 + (int)t;
+    const int64_t vox = ((int64_t)z * H + y) * W + x;
+    float a = acc[vox * lda + k];
+    float c = (cnt && k == 0) ? cnt[vox] : 0.f;
+    bool touched = false;
+    for (int w = 0; w < wl.n; ++w) {
+      const int lz = z - wl.z[w], ly = y - wl.y[w], lx = x - wl.x[w];
+      if ((unsigned)lz < (unsigned)rd && (unsigned)ly < (unsigned)rh && (unsigned)lx < (unsigned)rw) {
+        const int64_t lv = ((int64_t)lz * rh + ly) * rw + lx;
+        const float wt = imp ? imp[lv] : 1.f;
+        const float pv = Elem<T>::ld(pred + (((int64_t)w * rd * rh * rw) + lv) * ldp + k);
+        a += wt * pv;
+        c += wt;
+        touched = true;
+      }
+    }
+    if (touched) {
+      acc[vox * lda + k] = a;
+      if (cnt && k == 0) cnt[vox] = c;
+    }
+  }
+}
+
+template <typename T, typename L>
+__global__ void argmax_kernel(const T* __restrict__ lg, const float* __restrict__ cnt,
+                              float* __restrict__ wb, L* __restrict__ labels, int64_t nvox, int K,
+                              int ld) {
+  for (int64_t v = blockIdx.x * 256ll + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256) {
+    const T* p = lg + v * ld;
+    const float c = cnt ? cnt[v] : 1.f;
+    float best = 0.f;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      float x = Elem<T>::ld(p + k);
+      if (cnt) x = x / c;
+      if (wb) wb[v * ld + k] = x;
+      // torch.argmax: first maximal index; a NaN counts as maximal and the first one wins
+      if (k == 0) { best = x; }
+      else if (best == best && (x != x || x > best)) { best = x; bi = k; }
+    }
+    labels[v] = (L)bi;
+  }
+}
+
+__global__ void label_counts_kernel(const int32_t* __restrict__ pred, const int32_t* __restrict__ truth,
+                                    int64_t n, int K, unsigned long long* __restrict__ counts) {
+  extern __shared__ unsigned int hist[];  // [K][3]
+  for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) hist[i] = 0u;
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int a = pred[i], b = truth[i];
+    if ((unsigned)a < (unsigned)K) atomicAdd(&hist[a * 3 + 1], 1u);
+    if ((unsigned)b < (unsigned)K) atomicAdd(&hist[b * 3 + 2], 1u);
+    if (a == b && (unsigned)a < (unsigned)K) atomicAdd(&hist[a * 3 + 0], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * K; i += blockDim.x)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+struct CropList {
+  int n;
+  int b[kMaxWin], z[kMaxWin], y[kMaxWin], x[kMaxWin];
+  unsigned char flip[kMaxWin];
+};
+
+template <typename TD>
+__global__ void crop_kernel(const float* __restrict__ img, const float* __restrict__ lab, CropList cl,
+                            int D, int H, int W, int C, int ldi, TD* __restrict__ oimg,
+                            float* __restrict__ olab, int rd, int rh, int rw, int ldo) {
+  const int64_t per = (int64_t)rd * rh * rw;
+  const int64_t total = per * cl.n;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    int64_t t = e;
+    const int x = t % rw; t /= rw;
+    const int y = t % rh; t /= rh;
+    const int z = t % rd;
+    const int w = t / rd;
+    const unsigned char f = cl.flip[w];
+    const int sz = (f & 1) ? rd - 1 - z : z, sy = (f & 2) ? rh - 1 - y : y, sx = (f & 4) ? rw - 1 - x : x;
+    const int gz = cl.z[w] + sz, gy = cl.y[w] + sy, gx = cl.x[w] + sx;
+    const bool in = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int64_t gv = (((int64_t)cl.b[w] * D + gz) * H + gy) * W + gx;
+    for (int c = 0; c < C; ++c) Elem<TD>::st(oimg + e * ldo + c, in ? img[gv * ldi + c] : 0.f);
+    if (olab) olab[e] = (in && lab) ? lab[gv] : 0.f;
+  }
+}
+
+static inline int grid_for(int64_t total) {
+  const int64_t b = cdiv64(total, 256);
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace segmi
+
+using namespace segmi;
+
+extern "C" {
+
+int segmi_sw_gather(int dtype_src, const segmi_act* image, int img_index,
+                    const int32_t* starts_host, int nwin, int dst_dtype,
+                    const segmi_act* windows, void* stream) {
+  SEGMI_CHECK_ARG(act_ok(image) && act_ok(windows) && starts_host, "sw_gather: bad arguments");
+  SEGMI_CHECK_ARG(nwin > 0 && nwin <= kMaxWin && windows->n >= nwin, "sw_gather: 1..%d windows per call", kMaxWin);
+  SEGMI_CHECK_ARG(img_index >= 0 && img_index < image->n && image->c == windows->c, "sw_gather: image index / channels");
+  WinList wl{};
+  wl.n = nwin;
+  for (int i = 0; i < nwin; ++i) { wl.z[i] = starts_host[3 * i]; wl.y[i] = starts_host[3 * i + 1]; wl.x[i] = starts_host[3 * i + 2]; }
+  const int es = dtype_size(dtype_src);
+  const char* base = (const char*)image->data + (int64_t)img_index * image->d * image->h * image->w * image->ld * es;
+  const int64_t total = (int64_t)nwin * windows->d * windows->h * windows->w * windows->c;
+  const int grid = grid_for(total);
+  hipStream_t st = (hipStream_t)stream;
+#define GATHER(TS, TD)                                                                          \
+  hipLaunchKernelGGL((sw_gather_kernel<TS, TD>), grid, 256, 0, st, (const TS*)base,             \
+                     (TD*)windows->data, wl, image->d, image->h, image->w, image->c, image->ld, \
+                     windows->d, windows->h, windows->w, windows->ld)
+  if (dtype_src == SEGMI_F32 && dst_dtype == SEGMI_F32) GATHER(float, float);
+  else if (dtype_src == SEGMI_F32 && dst_dtype == SEGMI_BF16) GATHER(float, bf16_t);
+  else if (dtype_src == SEGMI_BF16 && dst_dtype == SEGMI_BF16) GATHER(bf16_t, bf16_t);
+  else if (dtype_src == SEGMI_BF16 && dst_dtype == SEGMI_F32) GATHER(bf16_t, float);
+  else SEGMI_CHECK_ARG(false, "sw_gather: bad dtypes");
+#undef GATHER
+  SEGMI_LAUNCH_CHECK("sw_gather");
+  return SEGMI_OK;
+}
+
+int segmi_sw_scatter_add(int dtype, const segmi_act* pred, const int32_t* starts_host,
+                         int nwin, const float* importance, const segmi_act* acc, float* cnt,
+                         void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "sw_scatter_add: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(pred) && act_ok(acc) && starts_host && acc->n == 1, "sw_scatter_add: bad arguments");
+  SEGMI_CHECK_ARG(nwin > 0 && nwin <= kMaxWin && pred->n >= nwin && pred->c == acc->c, "sw_scatter_add: windows / channels");
+  WinList wl{};
+  wl.n = nwin;
+  int z0 = 1 << 30, y0 = 1 << 30, x0 = 1 << 30, z1 = -(1 << 30), y1 = -(1 << 30), x1 = -(1 << 30);
+  for (int i = 0; i < nwin; ++i) {
+    wl.z[i] = starts_host[3 * i]; wl.y[i] = starts_host[3 * i + 1]; wl.x[i] = starts_host[3 * i + 2];
+    z0 = wl.z[i] < z0 ? wl.z[i] : z0; y0 = wl.y[i] < y0 ? wl.y[i] : y0; x0 = wl.x[i] < x0 ? wl.x[i] : x0;
+    z1 = wl.z[i] + pred->d > z1 ? wl.z[i] + pred->d : z1;
+    y1 = wl.y[i] + pred->h > y1 ? wl.y[i] + pred->h : y1;
+    x1 = wl.x[i] + pred->w > x1 ? wl.x[i] + pred->w : x1;
+  }
+  z0 = z0 < 0 ? 0 : z0; y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+  z1 = z1 > acc->d ? acc->d : z1; y1 = y1 > acc->h ? acc->h : y1; x1 = x1 > acc->w ? acc->w : x1;
+  if (z1 <= z0 || y1 <= y0 || x1 <= x0) return SEGMI_OK;
+  const int bd = z1 - z0, bh = y1 - y0, bw = x1 - x0;
+  const int grid = grid_for((int64_t)bd * bh * bw * acc->c);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SEGMI_F32)
+    hipLaunchKernelGGL(sw_scatter_kernel<float>, grid, 256, 0, st, (const float*)pred->data, wl, importance, (float*)acc->data, cnt, acc->d, acc->h, acc->w, acc->c, acc->ld, pred->d, pred->h, pred->w, pred->ld, z0, y0, x0, bd, bh, bw);
+  else
+    hipLaunchKernelGGL(sw_scatter_kernel<bf16_t>, grid, 256, 0, st, (const bf16_t*)pred->data, wl, importance, (float*)acc->data, cnt, acc->d, acc->h, acc->w, acc->c, acc->ld, pred->d, pred->h, pred->w, pred->ld, z0, y0, x0, bd, bh, bw);
+  SEGMI_LAUNCH_CHECK("sw_scatter_add");
+  return SEGMI_OK;
+}
+
+static int argmax_launch(int dtype, const segmi_act* lg, const float* cnt, int write_back,
+                         void* labels, int label_bytes, hipStream_t st) {
+  const int64_t nvox = act_voxels(lg);
+  const int grid = grid_for(nvox);
+  float* wb = write_back ? (float*)lg->data : nullptr;
+#define ARGMAX(T, L)                                                                     \
+  hipLaunchKernelGGL((argmax_kernel<T, L>), grid, 256, 0, st, (const T*)lg->data, cnt, wb, \
+                     (L*)labels, nvox, lg->c, lg->ld)
+  if (dtype == SEGMI_F32) {
+    if (label_bytes == 1) ARGMAX(float, uint8_t);
+    else if (label_bytes == 2) ARGMAX(float, int16_t);
+    else ARGMAX(float, int32_t);
+  } else {
+    if (label_bytes == 1) ARGMAX(bf16_t, uint8_t);
+    else if (label_bytes == 2) ARGMAX(bf16_t, int16_t);
+    else ARGMAX(bf16_t, int32_t);
+  }
+#undef ARGMAX
+  SEGMI_LAUNCH_CHECK("argmax");
+  return SEGMI_OK;
+}
+
+int segmi_sw_finalize(const segmi_act* acc, const float* cnt, int write_logits, void* labels,
+                      int label_bytes, void* stream) {
+  SEGMI_CHECK_ARG(act_ok(acc) && cnt && labels, "sw_finalize: bad arguments");
+  SEGMI_CHECK_ARG(label_bytes == 1 || label_bytes == 2 || label_bytes == 4, "sw_finalize: label_bytes");
+  SEGMI_CHECK_ARG(label_bytes > 1 || acc->c <= 256, "sw_finalize: uint8 labels hold at most 256 classes");
+  return argmax_launch(SEGMI_F32, acc, cnt, write_logits, labels, label_bytes, (hipStream_t)stream);
+}
+
+int segmi_argmax(int dtype, const segmi_act* logits, void* labels, int label_bytes, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "argmax: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(logits) && labels, "argmax: bad arguments");
+  SEGMI_CHECK_ARG(label_bytes == 1 || label_bytes == 2 || label_bytes == 4, "argmax: label_bytes");
+  return argmax_launch(dtype, logits, nullptr, 0, labels, label_bytes, (hipStream_t)stream);
+}
+
+int segmi_label_counts(const int32_t* pred, const int32_t* truth, int64_t n, int k,
+                       int64_t* counts, void* stream) {
+  SEGMI_CHECK_ARG(pred && truth && counts && n > 0 && k > 0 && k <= 4096, "label_counts: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(counts, 0, (size_t)k * 3 * 8, st) != hipSuccess) {
+    set_error("label_counts: memset failed");
+    return SEGMI_ELAUNCH;
+  }
+  const int grid = grid_for(n) > 1024 ? 1024 : grid_for(n);
+  hipLaunchKernelGGL(label_counts_kernel, grid, 256, (size_t)k * 3 * 4, st, pred, truth, n, k,
+                     (unsigned long long*)counts);
+  SEGMI_LAUNCH_CHECK("label_counts");
+  return SEGMI_OK;
+}
+
+int segmi_crop_patches(const segmi_act* image, const float* label, const int32_t* starts_host,
+                       const uint8_t* flips_host, int count, int dst_dtype,
+                       const segmi_act* out_image, float* out_label, void* stream) {
+  SEGMI_CHECK_ARG(act_ok(image) && act_ok(out_image) && starts_host, "crop_patches: bad arguments");
+  SEGMI_CHECK_ARG(count > 0 && count <= kMaxWin && out_image->n >= count && out_image->c == image->c,
+                  "crop_patches: 1..%d crops per call", kMaxWin);
+  CropList cl{};
+  cl.n = count;
+  for (int i = 0; i < count; ++i) {
+    cl.b[i] = starts_host[4 * i]; cl.z[i] = starts_host[4 * i + 1];
+    cl.y[i] = starts_host[4 * i + 2]; cl.x[i] = starts_host[4 * i + 3];
+    cl.flip[i] = flips_host ? flips_host[i] : 0;
+    SEGMI_CHECK_ARG(cl.b[i] >= 0 && cl.b[i] < image->n, "crop_patches: volume index out of range");
+  }
+  const int64_t total = (int64_t)count * out_image->d * out_image->h * out_image->w;
+  const int grid = grid_for(total);
+  hipStream_t st = (hipStream_t)stream;
+  if (dst_dtype == SEGMI_F32)
+    hipLaunchKernelGGL(crop_kernel<float>, grid, 256, 0, st, (const float*)image->data, label, cl, image->d, image->h, image->w, image->c, image->ld, (float*)out_image->data, out_label, out_image->d, out_image->h, out_image->w, out_image->ld);
+  else
+    hipLaunchKernelGGL(crop_kernel<bf16_t>, grid, 256, 0, st, (const float*)image->data, label, cl, image->d, image->h, image->w, image->c, image->ld, (bf16_t*)out_image->data, out_label, out_image->d, out_image->h, out_image->w, out_image->ld);
+  SEGMI_LAUNCH_CHECK("crop_patches");
+  return SEGMI_OK;
+}
+
+}  // extern "C"

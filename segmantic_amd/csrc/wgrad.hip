@@ -1,0 +1,158 @@
+// wgrad.hip -- weight / bias gradients: C entry points, the direct fallback, slab reduction.
+#include "wgrad_impl.h"
+
+namespace segmi {
+
+int wgrad_mfma_f32(const WgradParams& p, int stride, int ct, int gx, hipStream_t st);
+int wgrad_mfma_bf16(const WgradParams& p, int stride, int ct, int gx, hipStream_t st);
+int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
+int bn_stats_rows_for(const segmi_act* x);
+
+struct WgDirectParams {
+  const void* x;
+  const void* dy;
+  float* partials;
+  int N, Dx, Hx, Wx, Dy, Hy, Wy, Cin, Cout, ldx, ldy, ks, stride;
+  int64_t nvox;
+  int chunk;
+};
+
+// direct fallback: block b reduces voxel chunks b, b+grid, ...; thread loops outputs
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(WgDirectParams p) {
+  const int nt = p.ks * p.ks * p.ks, pad = (p.ks - 1) / 2;
+  const int nout = p.Cout * p.Cin * nt;
+  const T* x = (const T*)p.x;
+  const T* dy = (const T*)p.dy;
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const int tap = o % nt;
+    const int ci = (o / nt) % p.Cin;
+    const int co = o / (nt * p.Cin);
+    const int kd = tap / (p.ks * p.ks), kh = (tap / p.ks) % p.ks, kw = tap % p.ks;
+    float acc = 0.f;
+    for (int64_t c0 = (int64_t)blockIdx.x * p.chunk; c0 < p.nvox; c0 += (int64_t)gridDim.x * p.chunk) {
+      const int64_t c1 = c0 + p.chunk < p.nvox ? c0 + p.chunk : p.nvox;
+      for (int64_t v = c0; v < c1; ++v) {
+        int64_t t = v;
+        const int ox = t % p.Wy; t /= p.Wy;
+        const int oy = t % p.Hy; t /= p.Hy;
+        const int oz = t % p.Dy;
+        const int n = t / p.Dy;
+        const int z = oz * p.stride - pad + kd, y = oy * p.stride - pad + kh,
+                  xx = ox * p.stride - pad + kw;
+        if ((unsigned)z >= (unsigned)p.Dx || (unsigned)y >= (unsigned)p.Hx ||
+            (unsigned)xx >= (unsigned)p.Wx) continue;
+        const float a = Elem<T>::ld(dy + v * p.ldy + co);
+        const float b = Elem<T>::ld(x + ((((int64_t)n * p.Dx + z) * p.Hx + y) * p.Wx + xx) * p.ldx + ci);
+        acc = fmaf(a, b, acc);
+      }
+    }
+    p.partials[(int64_t)blockIdx.x * nout + o] = acc;
+  }
+}
+
+// out[e] = sum_b partials[b][e], fixed order, f64 accumulate
+__global__ void slab_reduce_kernel(const float* __restrict__ partials, int nslab, int64_t n,
+                                   float* __restrict__ out) {
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    double acc = 0.0;
+    for (int b = 0; b < nslab; ++b) acc += (double)partials[(int64_t)b * n + e];
+    out[e] = (float)acc;
+  }
+}
+
+// stats partials [rows][2][c] -> db[c] = sum of the "sum" rows
+__global__ void bias_reduce_kernel(const float* __restrict__ partials, int rows, int c,
+                                   float* __restrict__ db) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double acc = 0.0;
+  for (int r = 0; r < rows; ++r) acc += (double)partials[((int64_t)r * 2) * c + ch];
+  db[ch] = (float)acc;
+}
+
+static inline bool wg_mfma_ok(const segmi_act* x, const segmi_act* dy, int ksize) {
+  return ksize == 3 && x->c % 16 == 0 && dy->c % 16 == 0;
+}
+static inline int wg_direct_blocks(const segmi_act* dy) {
+  const int64_t b = cdiv64(act_voxels(dy), 512);
+  return (int)(b > 1024 ? 1024 : b);
+}
+static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace segmi
+
+using namespace segmi;
+
+extern "C" {
+
+int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_act* dy,
+                                     int ksize, int stride) {
+  if (!x || !dy) return 0;
+  const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
+  const int slabs = wg_mfma_ok(x, dy, ksize) ? wgrad_gx(dtype, x, dy, stride) : wg_direct_blocks(dy);
+  const int64_t bias = (int64_t)bn_stats_rows_for(dy) * 2 * dy->c * 4;
+  return align256(slabs * nout * 4) + align256(bias);
+}
+
+int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream) {
+  SEGMI_CHECK_ARG(act_ok(dy) && db && workspace, "bias_grad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = bn_stats_launch(dtype, dy, (float*)workspace, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bias_reduce_kernel, cdiv(dy->c, 256), 256, 0, st, (const float*)workspace,
+                     bn_stats_rows_for(dy), dy->c, db);
+  SEGMI_LAUNCH_CHECK("bias_grad");
+  return SEGMI_OK;
+}
+
+int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
+                       float* db, int ksize, int stride, void* workspace, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "wgrad: bad dtype");
+  SEGMI_CHECK_ARG(act_ok(x) && act_ok(dy) && dw && workspace, "wgrad: bad arguments");
+  SEGMI_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "wgrad: k/s");
+  const int pad = (ksize - 1) / 2;
+  SEGMI_CHECK_ARG(x->n == dy->n && dy->d == (x->d + 2 * pad - ksize) / stride + 1 &&
+                      dy->h == (x->h + 2 * pad - ksize) / stride + 1 &&
+                      dy->w == (x->w + 2 * pad - ksize) / stride + 1,
+                  "wgrad: dy extent does not match x for k%d s%d", ksize, stride);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
+  float* partials = (float*)workspace;
+  int slabs;
+  const int es = dtype_size(dtype);
+  if (wg_mfma_ok(x, dy, ksize)) {
+    SEGMI_CHECK_ARG(x->ld % (16 / es) == 0 && dy->ld % (16 / es) == 0 &&
+                        ((uintptr_t)x->data % 16) == 0 && ((uintptr_t)dy->data % 16) == 0,
+                    "wgrad: MFMA path needs 16-byte aligned rows");
+    WgradParams p{};
+    p.x = x->data; p.dy = dy->data; p.partials = partials;
+    p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
+    p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
+    const int ct = wgrad_ct(dtype, x->c, dy->c);
+    slabs = wgrad_gx(dtype, x, dy, stride);
+    const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, stride, ct, slabs, st)
+                                      : wgrad_mfma_bf16(p, stride, ct, slabs, st);
+    if (rc) return rc;
+  } else {
+    WgDirectParams p{};
+    p.x = x->data; p.dy = dy->data; p.partials = partials;
+    p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
+    p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld; p.ks = ksize; p.stride = stride;
+    p.nvox = act_voxels(dy); p.chunk = 512;
+    slabs = wg_direct_blocks(dy);
+    if (dtype == SEGMI_F32) hipLaunchKernelGGL(wgrad_direct_kernel<float>, slabs, 256, 0, st, p);
+    else hipLaunchKernelGGL(wgrad_direct_kernel<bf16_t>, slabs, 256, 0, st, p);
+    SEGMI_LAUNCH_CHECK("conv3d_wgrad(direct)");
+  }
+  const int rb = (int)(cdiv64(nout, 256) > 2048 ? 2048 : cdiv64(nout, 256));
+  hipLaunchKernelGGL(slab_reduce_kernel, rb, 256, 0, st, (const float*)partials, slabs, nout, dw);
+  SEGMI_LAUNCH_CHECK("conv3d_wgrad(reduce)");
+  if (db) {
+    float* bws = (float*)((char*)workspace + align256((int64_t)slabs * nout * 4));
+    return segmi_bias_grad(dtype, dy, db, bws, stream);
+  }
+  return SEGMI_OK;
+}
+
+}  // extern "C"

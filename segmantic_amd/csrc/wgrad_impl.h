@@ -1,0 +1,277 @@
+// wgrad_impl.h -- MFMA weight gradient of Conv3d k3 (stride 1 or 2).
+//
+//   dW[co][ci][tap] = sum_{n,vox} dY[n,vox,co] * X[n, vox*S + tap - 1, ci]
+//
+// GEMM with the huge voxel axis as K: D[co][ci] += A[co][k=vox] * B[k=vox][ci].  Both operands
+// need "8 voxels of one channel" per lane, i.e. the transpose of the NDHWC rows staged in LDS:
+//   bf16 -> ds_read_b64_tr_b16 (gfx950 transposing LDS read; 2 reads = one 16x16x32 operand)
+//   f32  -> ds_read_b32 gathers (one 16x16x4 operand each)
+// The k -> voxel assignment is free as long as A and B agree; we use voxel = 16h + 4g + q
+// (h = which tr-read, g = lane>>4, q = row the lane addresses) so that every 32-lane LDS
+// group touches 256 contiguous bytes (conflict-free for stride-1 convs).
+//
+// Work split: workgroup = (voxel-tile range) x (16*CT out-channels) x (16*CT in-channels);
+// its 4 waves own taps {w, w+4, ...} (7/7/7/6) so no cross-wave reduction is needed, and keep
+// their 7*CT*CT accumulators in registers across all tiles of the range (persistent loop).
+// Per-workgroup partial slabs are reduced in fixed order by wgrad_reduce_kernel: bitwise
+// reproducible, no atomics.
+#pragma once
+#include "common.h"
+
+namespace segmi {
+
+struct WgradParams {
+  const void* x;
+  const void* dy;
+  float* partials;
+  int N, Dx, Hx, Wx, Dy, Hy, Wy, Cin, Cout, ldx, ldy;
+  int tz, ty, tx;
+  int ntiles;
+  int ci_chunks;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) float lds_f32;
+
+template <typename T, int S, int CT, int TD, int TH, int TW>
+struct WgradGeom {
+  static constexpr int KS = 3, PAD = 1, NTAPS = 27;
+  static constexpr int NV = TD * TH * TW;
+  static constexpr int NL = NV / 16;  // 16-voxel lines
+  static constexpr int HD = (TD - 1) * S + KS, HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
+  static constexpr int ROWB = 16 * CT * (int)sizeof(T);
+  static constexpr int CPR = ROWB / 16;
+  static constexpr int YBYTES = NV * ROWB;
+  static constexpr int XROWS = HD * HH * HW;
+  static constexpr int LDS_BYTES = YBYTES + XROWS * ROWB;
+  static constexpr int LPG = sizeof(T) == 2 ? 2 : 1;  // lines per mma16
+  static_assert(NL % LPG == 0, "tile must hold whole k-steps");
+  static_assert(TW == 8 || TW == 16, "tile width");
+};
+
+// row (in X halo rows) of voxel `v` (0..15) of line `line`, before the tap offset
+template <int S, int TH, int TW, int HH, int HW>
+__device__ __forceinline__ constexpr int wg_line_row(int line) {
+  // a line is 16 consecutive voxel indices: TW=16 -> one x-row, TW=8 -> two x-rows
+  const int first = line * 16;
+  const int y = (first / TW) % TH, z = first / (TW * TH);
+  return (z * S * HH + y * S) * HW;
+}
+
+template <typename T, int S, int CT, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
+  using G = WgradGeom<T, S, CT, TD, TH, TW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ysm = smem;
+  char* xsm = smem + G::YBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i16 = lane & 15;
+
+  const int cochunk = blockIdx.y / p.ci_chunks, cichunk = blockIdx.y % p.ci_chunks;
+  const int co0 = cochunk * 16 * CT, ci0 = cichunk * 16 * CT;
+
+  f32x4 acc[7][CT][CT];
+#pragma unroll
+  for (int a = 0; a < 7; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // wave-uniform tap offsets (bytes into the X tile)
+  int tapoff[7];
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti) {
+    int tap = wave + 4 * ti;
+    if (tap > 26) tap = 26;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    tapoff[ti] = ((kd * G::HH + kh) * G::HW + kw) * G::ROWB;
+  }
+
+  // per-lane address parts
+  int ylane, xlane;
+  if constexpr (sizeof(T) == 2) {
+    const int q = i16 >> 2, pp = i16 & 3;
+    const int v = 4 * g + q;  // voxel within the line
+    ylane = v * G::ROWB + 8 * pp;
+    xlane = ((v / TW) * S * G::HW + (v % TW) * S) * G::ROWB + 8 * pp;
+  } else {
+    ylane = g * G::ROWB + 4 * i16;   // + 4u rows per sub-step
+    xlane = g * S * G::ROWB + 4 * i16;
+  }
+
+  const char* xb = (const char*)p.x;
+  const char* yb = (const char*)p.dy;
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int txi = t % p.tx; t /= p.tx;
+    const int tyi = t % p.ty; t /= p.ty;
+    const int tzi = t % p.tz;
+    const int n = t / p.tz;
+    const int oz0 = tzi * TD, oy0 = tyi * TH, ox0 = txi * TW;
+    const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    __syncthreads();
+    // stage dY tile [NV][16*CT]
+    for (int i = tid; i < G::NV * G::CPR; i += 256) {
+      const int v = i / G::CPR, ch = i % G::CPR;
+      const int z = oz0 + v / (TW * TH), y = oy0 + (v / TW) % TH, x = ox0 + v % TW;
+      frag_t val = frag_t{0u, 0u, 0u, 0u};
+      if (z < p.Dy && y < p.Hy && x < p.Wy) {
+        const int64_t e = ((((int64_t)n * p.Dy + z) * p.Hy + y) * p.Wy + x) * p.ldy + co0;
+        val = *reinterpret_cast<const frag_t*>(yb + e * (int64_t)sizeof(T) + ch * 16);
+      }
+      *reinterpret_cast<frag_t*>(ysm + v * G::ROWB + ch * 16) = val;
+    }
+    // stage X halo tile [HD*HH*HW][16*CT]
+    for (int i = tid; i < G::XROWS * G::CPR; i += 256) {
+      const int v = i / G::CPR, ch = i % G::CPR;
+      const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
+      const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
+      frag_t val = frag_t{0u, 0u, 0u, 0u};
+      if ((unsigned)z < (unsigned)p.Dx && (unsigned)y < (unsigned)p.Hx &&
+          (unsigned)x < (unsigned)p.Wx) {
+        const int64_t e = ((((int64_t)n * p.Dx + z) * p.Hx + y) * p.Wx + x) * p.ldx + ci0;
+        val = *reinterpret_cast<const frag_t*>(xb + e * (int64_t)sizeof(T) + ch * 16);
+      }
+      *reinterpret_cast<frag_t*>(xsm + v * G::ROWB + ch * 16) = val;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int lg = 0; lg < G::NL / G::LPG; ++lg) {
+      frag_t af[CT];
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4*)(ysm + ylane + (2 * lg) * 16 * G::ROWB + ct * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4*)(ysm + ylane + (2 * lg + 1) * 16 * G::ROWB + ct * 32));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          af[ct] = frag_t{l2[0], l2[1], h2[0], h2[1]};
+        }
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            af[ct][u] = __float_as_uint(*(lds_f32*)(ysm + ylane + (lg * 16 + 4 * u) * G::ROWB + ct * 64));
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < 7; ++ti) {
+        frag_t bf[CT];
+        if constexpr (sizeof(T) == 2) {
+          const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg) * G::ROWB;
+          const int r1 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg + 1) * G::ROWB;
+#pragma unroll
+          for (int it = 0; it < CT; ++it) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4*)(xsm + xlane + tapoff[ti] + r0 + it * 32));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4*)(xsm + xlane + tapoff[ti] + r1 + it * 32));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            bf[it] = frag_t{l2[0], l2[1], h2[0], h2[1]};
+          }
+        } else {
+          const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(lg) * G::ROWB;
+#pragma unroll
+          for (int it = 0; it < CT; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              // voxel 4u+g of the line: TW=16 -> same x-row; TW=8 -> rows u>>1
+              const int vo = TW == 16 ? 4 * u * S : ((u >> 1) * S * G::HW + 4 * (u & 1) * S);
+              bf[it][u] = __float_as_uint(
+                  *(lds_f32*)(xsm + xlane + tapoff[ti] + r0 + vo * G::ROWB + it * 64));
+            }
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int it = 0; it < CT; ++it) acc[ti][ct][it] = mma16<T>(af[ct], bf[it], acc[ti][ct][it]);
+      }
+    }
+  }
+
+  // partial slab [block][Cout][Cin][27]
+  float* slab = p.partials + (int64_t)blockIdx.x * p.Cout * p.Cin * 27;
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti) {
+    const int tap = wave + 4 * ti;
+    if (tap < 27) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int it = 0; it < CT; ++it)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = co0 + ct * 16 + 4 * g + e, ci = ci0 + it * 16 + i16;
+            slab[((int64_t)co * p.Cin + ci) * 27 + tap] = acc[ti][ct][it][e];
+          }
+    }
+  }
+}
+
+template <typename T, int S, int CT, int TD, int TH, int TW>
+static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
+  using G = WgradGeom<T, S, CT, TD, TH, TW>;
+  p.tz = cdiv(p.Dy, TD);
+  p.ty = cdiv(p.Hy, TH);
+  p.tx = cdiv(p.Wy, TW);
+  p.ntiles = p.N * p.tz * p.ty * p.tx;
+  p.ci_chunks = p.Cin / (16 * CT);
+  const int co_chunks = p.Cout / (16 * CT);
+  dim3 grid((unsigned)gx_hint, (unsigned)(co_chunks * p.ci_chunks));
+  auto kern = wgrad_mfma_kernel<T, S, CT, TD, TH, TW>;
+  static bool attr_done = false;
+  if (!attr_done && G::LDS_BYTES > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES, st, p);
+  SEGMI_LAUNCH_CHECK("conv3d_wgrad(mfma)");
+  return SEGMI_OK;
+}
+
+// how many voxel-range workgroups (= partial slabs) the MFMA path uses
+static inline int wgrad_tiles(const segmi_act* dy, int stride) {
+  const bool wide = dy->w > 8;
+  int td, th, tw;
+  if (stride == 1) { td = wide ? 2 : 4; th = 8; tw = wide ? 16 : 8; }
+  else { td = 2; th = wide ? 4 : 8; tw = wide ? 16 : 8; }
+  return dy->n * cdiv(dy->d, td) * cdiv(dy->h, th) * cdiv(dy->w, tw);
+}
+static inline int wgrad_ct(int dtype, int cin, int cout) {
+  return (dtype == SEGMI_BF16 && cin % 32 == 0 && cout % 32 == 0) ? 2 : 1;
+}
+static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int stride) {
+  const int ct = wgrad_ct(dtype, x->c, dy->c);
+  const int chunks = (x->c / (16 * ct)) * (dy->c / (16 * ct));
+  int gx = 512 / chunks;
+  if (gx < 1) gx = 1;
+  const int nt = wgrad_tiles(dy, stride);
+  return gx < nt ? gx : nt;
+}
+
+template <typename T>
+static int launch_wgrad_mfma_t(const WgradParams& p, int stride, int ct, int gx, hipStream_t st) {
+  const bool wide = p.Wy > 8;
+  if constexpr (sizeof(T) == 2) {
+    if (ct == 2) {
+      if (stride == 1) return wide ? launch_wgrad_cfg<T, 1, 2, 2, 8, 16>(p, gx, st)
+                                   : launch_wgrad_cfg<T, 1, 2, 4, 8, 8>(p, gx, st);
+      return wide ? launch_wgrad_cfg<T, 2, 2, 2, 4, 16>(p, gx, st)
+                  : launch_wgrad_cfg<T, 2, 2, 2, 8, 8>(p, gx, st);
+    }
+  }
+  if (stride == 1) return wide ? launch_wgrad_cfg<T, 1, 1, 2, 8, 16>(p, gx, st)
+                               : launch_wgrad_cfg<T, 1, 1, 4, 8, 8>(p, gx, st);
+  return wide ? launch_wgrad_cfg<T, 2, 1, 2, 4, 16>(p, gx, st)
+              : launch_wgrad_cfg<T, 2, 1, 2, 8, 8>(p, gx, st);
+}
+
+}  // namespace segmi

@@ -1,0 +1,351 @@
+"""Thin torch-tensor wrappers over the C-ABI of ``libsegmi.so``.
+
+PyTorch is plumbing here (device memory, streams): every function below hands raw device
+pointers + extents to a HIP kernel and returns.  Activations are ``[N, D, H, W, C]`` tensors
+(NDHWC); a channel slice ``t[..., a:b]`` of such a tensor is a valid view (concat by offset).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SEGMI_BF16, SEGMI_F32, Act, check, lib
+
+_DT = {torch.float32: SEGMI_F32, torch.bfloat16: SEGMI_BF16}
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_device(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            "segmantic_amd ops run on an MI355X only (tensor is on %s); there is no CPU path"
+            % t.device)
+
+
+def act(t: torch.Tensor) -> Act:
+    """NDHWC view descriptor of a 5-D tensor whose last dim has stride 1."""
+    _require_device(t)
+    if t.dim() != 5:
+        raise ValueError(f"expected a 5-D NDHWC tensor, got shape {tuple(t.shape)}")
+    n, d, h, w, c = t.shape
+    sn, sd, sh, sw, sc = t.stride()
+    ld = sw
+    if c > 1 and sc != 1:
+        raise ValueError("channel dim must be contiguous")
+    if w == 1:
+        ld = max(ld, c)
+    if not (sh == w * ld or h == 1) or not (sd == h * w * ld or d == 1) or \
+            not (sn == d * h * w * ld or n == 1):
+        raise ValueError(f"tensor is not a dense NDHWC view: shape {tuple(t.shape)} "
+                         f"stride {t.stride()}")
+    return Act(t.data_ptr(), n, d, h, w, c, ld)
+
+
+def _ref(a: Optional[Act]):
+    return C.byref(a) if a is not None else None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    _require_device(t)
+    return C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------ weights
+def wpack_bytes(dtype: torch.dtype, kind: int, cin_k: int, cout_k: int, ksize: int) -> int:
+    return int(lib.segmi_wpack_bytes(_DT[dtype], kind, cin_k, cout_k, ksize))
+
+
+def wpack(dtype: torch.dtype, kind: int, w_src: torch.Tensor, cin_k: int, cout_k: int,
+          ksize: int, scale: Optional[torch.Tensor] = None,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    nbytes = wpack_bytes(dtype, kind, cin_k, cout_k, ksize)
+    if nbytes <= 0:
+        raise ValueError(f"no MFMA pack for cin={cin_k} cout={cout_k}")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w_src.device)
+    check(lib.segmi_wpack(_DT[dtype], kind, _ptr(w_src), _ptr(scale), cin_k, cout_k, ksize,
+                          _ptr(out), _stream()), "wpack")
+    return out
+
+
+def mfma_ok(cin: int, cout: int) -> bool:
+    return cin % 16 == 0 and cout % 16 == 0
+
+
+# ------------------------------------------------------------------ convolution
+def conv3d_stats_rows(x, y, ksize, stride) -> int:
+    ax, ay = act(x), act(y)
+    return int(lib.segmi_conv3d_stats_rows(dtype_code(x), C.byref(ax), C.byref(ay), ksize,
+                                           stride))
+
+
+def conv3d_fwd(x, y, packed, w_src, w_kind, bias, ksize, stride, prelu_alpha=None,
+               residual=None, stats=None) -> None:
+    ax, ay = act(x), act(y)
+    ar = act(residual) if residual is not None else None
+    check(lib.segmi_conv3d_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed),
+                               _ptr(w_src), w_kind, _ptr(bias), _ptr(prelu_alpha), _ref(ar),
+                               _ptr(stats), ksize, stride, _stream()), "conv3d_fwd")
+
+
+def convT3d_stats_rows(x, y) -> int:
+    ax, ay = act(x), act(y)
+    return int(lib.segmi_convT3d_stats_rows(dtype_code(x), C.byref(ax), C.byref(ay)))
+
+
+def convT3d_fwd(x, y, packed, w_src, bias, prelu_alpha=None, residual=None, stats=None) -> None:
+    ax, ay = act(x), act(y)
+    ar = act(residual) if residual is not None else None
+    check(lib.segmi_convT3d_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed),
+                                _ptr(w_src), _ptr(bias), _ptr(prelu_alpha), _ref(ar),
+                                _ptr(stats), _stream()), "convT3d_fwd")
+
+
+def conv3d_wgrad_workspace(x, dy, ksize, stride) -> int:
+    ax, ay = act(x), act(dy)
+    return int(lib.segmi_conv3d_wgrad_workspace(dtype_code(x), C.byref(ax), C.byref(ay), ksize,
+                                                stride))
+
+
+def conv3d_wgrad(x, dy, dw, db, ksize, stride, workspace) -> None:
+    ax, ay = act(x), act(dy)
+    check(lib.segmi_conv3d_wgrad(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(dw), _ptr(db),
+                                 ksize, stride, _ptr(workspace), _stream()), "conv3d_wgrad")
+
+
+def bias_grad(dy, db, workspace) -> None:
+    ay = act(dy)
+    check(lib.segmi_bias_grad(dtype_code(dy), C.byref(ay), _ptr(db), _ptr(workspace),
+                              _stream()), "bias_grad")
+
+
+# ------------------------------------------------------------------ norm + activation
+def bn_stats_rows(x) -> int:
+    ax = act(x)
+    return int(lib.segmi_bn_stats_rows(C.byref(ax)))
+
+
+def bn_stats(x, partials) -> None:
+    ax = act(x)
+    check(lib.segmi_bn_stats(dtype_code(x), C.byref(ax), _ptr(partials), _stream()), "bn_stats")
+
+
+def bn_finalize(partials, rows, c, count, gamma, beta, running_mean, running_var, momentum,
+                eps, mean, invstd, scale, shift) -> None:
+    check(lib.segmi_bn_finalize(_ptr(partials), rows, c, float(count), _ptr(gamma), _ptr(beta),
+                                _ptr(running_mean), _ptr(running_var), momentum, eps,
+                                _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), _stream()),
+          "bn_finalize")
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift) -> None:
+    check(lib.segmi_bn_eval_affine(running_mean.numel(), _ptr(gamma), _ptr(beta),
+                                   _ptr(running_mean), _ptr(running_var), eps, _ptr(scale),
+                                   _ptr(shift), _stream()), "bn_eval_affine")
+
+
+def bn_act_fwd(x, y, scale, shift, prelu_alpha=None, residual=None) -> None:
+    ax, ay = act(x), act(y)
+    ar = act(residual) if residual is not None else None
+    check(lib.segmi_bn_act_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(scale),
+                               _ptr(shift), _ptr(prelu_alpha), _ref(ar), _stream()),
+          "bn_act_fwd")
+
+
+def bn_act_bwd_rows(x) -> int:
+    ax = act(x)
+    return int(lib.segmi_bn_act_bwd_rows(C.byref(ax)))
+
+
+def bn_act_bwd_reduce(dy, x, mean, invstd, gamma, beta, prelu_alpha, partials) -> None:
+    ady, ax = act(dy), act(x)
+    check(lib.segmi_bn_act_bwd_reduce(dtype_code(x), C.byref(ady), C.byref(ax), _ptr(mean),
+                                      _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(prelu_alpha),
+                                      _ptr(partials), _stream()), "bn_act_bwd_reduce")
+
+
+def bn_act_bwd_finalize(partials, rows, c, count, gamma, invstd, dgamma, dbeta, dalpha,
+                        coef) -> None:
+    check(lib.segmi_bn_act_bwd_finalize(_ptr(partials), rows, c, float(count), _ptr(gamma),
+                                        _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha),
+                                        _ptr(coef), _stream()), "bn_act_bwd_finalize")
+
+
+def bn_act_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, coef) -> None:
+    ady, ax, adx = act(dy), act(x), act(dx)
+    check(lib.segmi_bn_act_bwd_apply(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx),
+                                     _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                     _ptr(prelu_alpha), _ptr(coef), _stream()),
+          "bn_act_bwd_apply")
+
+
+def add(a, b, out) -> None:
+    aa, ao = act(a), act(out)
+    ab = act(b) if b is not None else None
+    check(lib.segmi_add(dtype_code(a), C.byref(aa), _ref(ab), C.byref(ao), _stream()), "add")
+
+
+def cast_copy(src, dst) -> None:
+    a, b = act(src), act(dst)
+    check(lib.segmi_cast_copy(dtype_code(src), C.byref(a), dtype_code(dst), C.byref(b),
+                              _stream()), "cast_copy")
+
+
+def nchw_to_ndhwc(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """src f32 [N,C,D,H,W] contiguous -> dst NDHWC (f32 or bf16)."""
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        raise ValueError("nchw_to_ndhwc expects a contiguous float32 NCDHW tensor")
+    b = act(dst)
+    check(lib.segmi_nchw_to_ndhwc(_ptr(src), dtype_code(dst), C.byref(b), _stream()),
+          "nchw_to_ndhwc")
+
+
+def ndhwc_to_nchw(src: torch.Tensor, dst: torch.Tensor) -> None:
+    a = act(src)
+    if dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise ValueError("ndhwc_to_nchw writes a contiguous float32 NCDHW tensor")
+    check(lib.segmi_ndhwc_to_nchw(dtype_code(src), C.byref(a), _ptr(dst), _stream()),
+          "ndhwc_to_nchw")
+
+
+# ------------------------------------------------------------------ loss + optimiser
+def dice_chunks(logits) -> int:
+    a = act(logits)
+    return int(lib.segmi_dice_chunks(C.byref(a)))
+
+
+def softmax_dice_fwd(logits, labels, partials, coef, loss, smooth_nr=1e-5, smooth_dr=1e-5):
+    a = act(logits)
+    check(lib.segmi_softmax_dice_fwd(dtype_code(logits), C.byref(a), _ptr(labels),
+                                     _ptr(partials), _ptr(coef), _ptr(loss), smooth_nr,
+                                     smooth_dr, _stream()), "softmax_dice_fwd")
+
+
+def softmax_dice_bwd(logits, labels, coef, grad_scale, dlogits) -> None:
+    a, b = act(logits), act(dlogits)
+    check(lib.segmi_softmax_dice_bwd(dtype_code(logits), C.byref(a), _ptr(labels), _ptr(coef),
+                                     float(grad_scale), C.byref(b), _stream()),
+          "softmax_dice_bwd")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps,
+              weight_decay, step, grad_scale=1.0) -> None:
+    check(lib.segmi_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                              _ptr(max_exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
+                              weight_decay, step, grad_scale, _stream()), "adam_step")
+
+
+def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0) -> None:
+    check(lib.segmi_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), lr, momentum,
+                             weight_decay, int(first_step), grad_scale, _stream()), "sgd_step")
+
+
+def adabelief_step(param, grad, exp_avg, exp_avg_var, lr, beta1, beta2, eps, weight_decay,
+                   weight_decouple, step, grad_scale=1.0) -> None:
+    check(lib.segmi_adabelief_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_var),
+                                   param.numel(), lr, beta1, beta2, eps, weight_decay,
+                                   int(weight_decouple), step, grad_scale, _stream()),
+          "adabelief_step")
+
+
+# ------------------------------------------------------------------ sliding window
+def _starts(starts: Sequence[Sequence[int]], width: int):
+    arr = np.ascontiguousarray(np.asarray(starts, dtype=np.int32).reshape(-1, width))
+    return arr, arr.ctypes.data_as(C.c_void_p)
+
+
+def sw_gather(image, img_index, starts, windows) -> None:
+    a, b = act(image), act(windows)
+    arr, p = _starts(starts, 3)
+    check(lib.segmi_sw_gather(dtype_code(image), C.byref(a), img_index, p, arr.shape[0],
+                              dtype_code(windows), C.byref(b), _stream()), "sw_gather")
+
+
+def sw_scatter_add(pred, starts, acc, cnt, importance=None) -> None:
+    a, b = act(pred), act(acc)
+    arr, p = _starts(starts, 3)
+    check(lib.segmi_sw_scatter_add(dtype_code(pred), C.byref(a), p, arr.shape[0],
+                                   _ptr(importance), C.byref(b), _ptr(cnt), _stream()),
+          "sw_scatter_add")
+
+
+_LABEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4}
+
+
+def sw_finalize(acc, cnt, labels, write_logits=True) -> None:
+    a = act(acc)
+    check(lib.segmi_sw_finalize(C.byref(a), _ptr(cnt), int(write_logits), _ptr(labels),
+                                _LABEL_BYTES[labels.dtype], _stream()), "sw_finalize")
+
+
+def argmax(logits, labels) -> None:
+    a = act(logits)
+    check(lib.segmi_argmax(dtype_code(logits), C.byref(a), _ptr(labels),
+                           _LABEL_BYTES[labels.dtype], _stream()), "argmax")
+
+
+def label_counts(pred, truth, k, counts) -> None:
+    check(lib.segmi_label_counts(_ptr(pred), _ptr(truth), pred.numel(), k, _ptr(counts),
+                                 _stream()), "label_counts")
+
+
+# ------------------------------------------------------------------ image ops
+_PIXEL = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.int32: 3, torch.uint16: 4}
+
+
+def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, default=0.0):
+    """src [z,y,x] -> dst [z,y,x]; index_map: 3x4 out-index(x,y,z,1) -> in-index(x,y,z)."""
+    _require_device(src)
+    if src.dim() != 3 or not src.is_contiguous():
+        raise ValueError("resample3d expects a contiguous [z,y,x] tensor")
+    dz, dy, dx = (int(v) for v in out_size_zyx)
+    dst = torch.empty((dz, dy, dx), dtype=src.dtype, device=src.device)
+    m = np.ascontiguousarray(np.asarray(index_map, dtype=np.float64).reshape(12))
+    sz, sy, sx = src.shape
+    check(lib.segmi_resample3d(_PIXEL[src.dtype], _ptr(src), sx, sy, sz, _ptr(dst), dx, dy, dz,
+                               m.ctypes.data_as(C.c_void_p), 1 if nearest else 0,
+                               float(default), _stream()), "resample3d")
+    return dst
+
+
+def normalize_intensity_(x: torch.Tensor) -> torch.Tensor:
+    """in-place channel-wise (x-mean)/std of a contiguous f32 [C, ...] tensor."""
+    _require_device(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("normalize_intensity_ expects contiguous float32")
+    c = x.shape[0]
+    nvox = x.numel() // c
+    ws = torch.empty(int(lib.segmi_normalize_workspace(c, nvox)), dtype=torch.uint8,
+                     device=x.device)
+    check(lib.segmi_normalize_intensity(_ptr(x), c, nvox, _ptr(ws), _stream()),
+          "normalize_intensity")
+    return x
+
+
+def crop_patches(image, label, starts, flips, out_image, out_label) -> None:
+    a, b = act(image), act(out_image)
+    arr, p = _starts(starts, 4)
+    fl = None
+    flp = None
+    if flips is not None:
+        fl = np.ascontiguousarray(np.asarray(flips, dtype=np.uint8))
+        flp = fl.ctypes.data_as(C.c_void_p)
+    check(lib.segmi_crop_patches(C.byref(a), _ptr(label), p, flp, arr.shape[0],
+                                 dtype_code(out_image), C.byref(b), _ptr(out_label),
+                                 _stream()), "crop_patches")

@@ -1,0 +1,402 @@
+"""GPU parity of every HIP op against the CPU oracle operators (torch CPU fp32 = what MONAI's
+UNet / DiceLoss reduce to, see oracle/unet_ref.py).  Tolerances are written next to each check:
+f32 kernels are exact-f32 MFMA chains (only the summation order differs from oneDNN), bf16
+kernels are compared against the oracle evaluated on bf16-rounded inputs.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from segmantic_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+F32_RTOL = 2e-5      # f32 path: relative to max |ref|
+BF16_RTOL = 1.5e-2   # bf16 path: output rounding (2^-8) + accumulate-order noise
+
+
+def to_ndhwc(x_ncdhw, dtype):
+    return x_ncdhw.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+
+
+def from_ndhwc(t):
+    return t.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def q(x, dtype):
+    return x.to(dtype).float()
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def tol(dtype):
+    return F32_RTOL if dtype == torch.float32 else BF16_RTOL
+
+
+CONV_CASES = [
+    # cin, cout, k, s, spatial (d,h,w), batch
+    (16, 16, 3, 1, (8, 12, 20), 2),
+    (16, 32, 3, 2, (10, 12, 36), 1),
+    (32, 32, 3, 1, (6, 6, 8), 2),
+    (32, 64, 3, 2, (8, 8, 16), 1),
+    (64, 64, 3, 1, (4, 4, 8), 1),
+    (128, 256, 1, 1, (4, 4, 4), 2),
+    (16, 48, 3, 1, (5, 9, 17), 1),
+    (1, 16, 3, 2, (12, 12, 12), 2),   # direct kernel (first layer)
+    (16, 3, 3, 1, (6, 7, 9), 1),      # direct kernel (K=3 head)
+    (4, 8, 3, 2, (9, 9, 9), 1),       # direct kernel, odd extents
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd(case, dtype):
+    cin, cout, k, s, sp, n = case
+    x = rnd((n, cin) + sp, 1)
+    w = rnd((cout, cin, k, k, k), 2, 1.0 / math.sqrt(cin * k ** 3))
+    b = rnd((cout,), 3, 0.1)
+    ref = F.conv3d(q(x, dtype), q(w, dtype), b, stride=s, padding=(k - 1) // 2)
+    xd = to_ndhwc(x, dtype)
+    yd = torch.empty((n,) + tuple(ref.shape[2:]) + (cout,), dtype=dtype, device=DEV)
+    wd, bd = w.to(DEV), b.to(DEV)
+    packed = ops.wpack(dtype, 0, wd, cin, cout, k) if ops.mfma_ok(cin, cout) else None
+    rows = ops.conv3d_stats_rows(xd, yd, k, s)
+    stats = torch.zeros((rows, 2, cout), device=DEV)
+    ops.conv3d_fwd(xd, yd, packed, wd, 0, bd, k, s, stats=stats)
+    torch.cuda.synchronize()
+    got = from_ndhwc(yd)
+    assert relerr(got, ref) < tol(dtype)
+    # fused statistics: per-channel sum / sum of squares of the (pre-rounding) conv output
+    ssum = stats[:, 0].double().sum(0).cpu()
+    ssq = stats[:, 1].double().sum(0).cpu()
+    rs = ref.double().sum((0, 2, 3, 4))
+    rq = (ref.double() ** 2).sum((0, 2, 3, 4))
+    cnt = ref.numel() / cout
+    assert float((ssum - rs).abs().max()) / cnt < (1e-5 if dtype == torch.float32 else 2e-2) * float(ref.abs().max())
+    assert float(((ssq - rq).abs() / rq).max()) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_epilogue_prelu_residual_and_views(dtype):
+    """PReLU + residual epilogue, reading from / writing into channel slices (concat by offset)."""
+    n, cin, cout, sp = 1, 16, 16, (6, 10, 18)
+    x = rnd((n, cin) + sp, 5)
+    w = rnd((cout, cin, 3, 3, 3), 6, 0.05)
+    b = rnd((cout,), 7, 0.1)
+    r = rnd((n, cout) + sp, 8)
+    alpha = 0.2
+    ref = F.prelu(F.conv3d(q(x, dtype), q(w, dtype), b, padding=1), torch.tensor([alpha])) + q(r, dtype)
+    big_in = torch.zeros((n,) + sp + (48,), dtype=dtype, device=DEV)
+    big_in[..., 16:32] = to_ndhwc(x, dtype)
+    big_out = torch.zeros((n,) + sp + (32,), dtype=dtype, device=DEV)
+    rd = to_ndhwc(r, dtype)
+    wd, bd = w.to(DEV), b.to(DEV)
+    ad = torch.tensor([alpha], device=DEV)
+    packed = ops.wpack(dtype, 0, wd, cin, cout, 3)
+    ops.conv3d_fwd(big_in[..., 16:32], big_out[..., 16:32], packed, None, 0, bd, 3, 1,
+                   prelu_alpha=ad, residual=rd)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(big_out[..., 16:32]), ref) < tol(dtype)
+    assert float(big_out[..., :16].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(16, 16, (6, 8, 20), 2), (32, 16, (4, 6, 8), 1), (4, 8, (5, 5, 5), 1)])
+def test_conv3d_dgrad_s1(case, dtype):
+    """stride-1 dgrad = conv with flipped / transposed weights (pack kind 1)."""
+    cin, cout, sp, n = case
+    w = rnd((cout, cin, 3, 3, 3), 11, 0.05)
+    dy = rnd((n, cout) + sp, 12)
+    ref = F.conv_transpose3d(q(dy, dtype), q(w, dtype), stride=1, padding=1)
+    dyd = to_ndhwc(dy, dtype)
+    dxd = torch.empty((n,) + sp + (cin,), dtype=dtype, device=DEV)
+    wd = w.to(DEV)
+    packed = ops.wpack(dtype, 1, wd, cout, cin, 3) if ops.mfma_ok(cin, cout) else None
+    ops.conv3d_fwd(dyd, dxd, packed, wd, 1, None, 3, 1)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(dxd), ref) < tol(dtype)
+
+
+CONVT_CASES = [
+    (32, 16, (6, 6, 20), 2, 0),
+    (64, 16, (4, 6, 8), 1, 0),
+    (16, 32, (5, 4, 9), 1, 0),
+    (16, 16, (3, 5, 17), 1, 1),   # odd output extent (2*in - 1): dgrad of a conv on odd input
+    (384, 64, (4, 4, 4), 1, 0),
+    (8, 4, (4, 5, 6), 2, 0),      # direct kernel
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_convT3d_fwd(case, dtype):
+    cin, cout, sp, n, odd = case
+    x = rnd((n, cin) + sp, 21)
+    w = rnd((cin, cout, 3, 3, 3), 22, 1.0 / math.sqrt(cin * 27 / 8))
+    b = rnd((cout,), 23, 0.1)
+    ref = F.conv_transpose3d(q(x, dtype), q(w, dtype), b, stride=2, padding=1,
+                             output_padding=0 if odd else 1)
+    xd = to_ndhwc(x, dtype)
+    yd = torch.empty((n,) + tuple(ref.shape[2:]) + (cout,), dtype=dtype, device=DEV)
+    wd, bd = w.to(DEV), b.to(DEV)
+    packed = ops.wpack(dtype, 2, wd, cin, cout, 3) if ops.mfma_ok(cin, cout) else None
+    rows = ops.convT3d_stats_rows(xd, yd)
+    stats = torch.zeros((rows, 2, cout), device=DEV)
+    ops.convT3d_fwd(xd, yd, packed, wd, bd, stats=stats)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(yd), ref) < tol(dtype)
+    ssum = stats[:, 0].double().sum(0).cpu()
+    rs = ref.double().sum((0, 2, 3, 4))
+    assert float((ssum - rs).abs().max()) / (ref.numel() / cout) < (1e-5 if dtype == torch.float32 else 2e-2) * float(ref.abs().max())
+
+
+WGRAD_CASES = [
+    (16, 16, 3, 1, (4, 16, 32), 2),
+    (16, 32, 3, 2, (8, 8, 32), 1),
+    (32, 32, 3, 1, (4, 8, 8), 2),
+    (64, 32, 3, 2, (8, 16, 16), 1),
+    (32, 64, 3, 1, (5, 7, 9), 1),
+    (1, 16, 3, 2, (12, 12, 12), 2),   # direct
+    (128, 256, 1, 1, (4, 4, 4), 2),   # direct (k1)
+    (16, 3, 3, 1, (6, 6, 6), 1),      # direct
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv3d_wgrad(case, dtype):
+    cin, cout, k, s, sp, n = case
+    x = rnd((n, cin) + sp, 31)
+    osp = tuple((d + 2 * ((k - 1) // 2) - k) // s + 1 for d in sp)
+    dy = rnd((n, cout) + osp, 32)
+    xq = q(x, dtype).requires_grad_(False)
+    w0 = torch.zeros((cout, cin, k, k, k), requires_grad=True)
+    b0 = torch.zeros((cout,), requires_grad=True)
+    F.conv3d(xq, w0, b0, stride=s, padding=(k - 1) // 2).backward(q(dy, dtype))
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    dw = torch.empty_like(w0, device=DEV)
+    db = torch.empty_like(b0, device=DEV)
+    ws = torch.empty(ops.conv3d_wgrad_workspace(xd, dyd, k, s), dtype=torch.uint8, device=DEV)
+    ops.conv3d_wgrad(xd, dyd, dw, db, k, s, ws)
+    torch.cuda.synchronize()
+    # bf16 inputs are exact products in f32; only summation order differs
+    assert relerr(dw.cpu(), w0.grad) < 5e-5
+    assert relerr(db.cpu(), b0.grad) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convT3d_wgrad_via_conv_wgrad(dtype):
+    """ConvTranspose3d weight grad == stride-2 conv wgrad with x := dy_T, dy := x_T."""
+    n, cin, cout, sp = 1, 32, 16, (4, 6, 10)
+    x = rnd((n, cin) + sp, 41)
+    w0 = torch.zeros((cin, cout, 3, 3, 3), requires_grad=True)
+    y = F.conv_transpose3d(q(x, dtype), w0, stride=2, padding=1, output_padding=1)
+    dy = rnd(tuple(y.shape), 42)
+    y.backward(q(dy, dtype))
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    dw = torch.empty_like(w0, device=DEV)
+    ws = torch.empty(ops.conv3d_wgrad_workspace(dyd, xd, 3, 2), dtype=torch.uint8, device=DEV)
+    ops.conv3d_wgrad(dyd, xd, dw, None, 3, 2, ws)
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), w0.grad) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c", [16, 32, 3])
+def test_bn_prelu_fwd_bwd(dtype, c):
+    n, sp = 2, (6, 10, 14)
+    x = rnd((n, c) + sp, 51, 2.0)
+    gamma = 1 + 0.2 * rnd((c,), 52)
+    beta = 0.1 * rnd((c,), 53)
+    alpha = torch.tensor([0.25])
+    res = rnd((n, c) + sp, 54)
+    dy = rnd((n, c) + sp, 55)
+    xq = q(x, dtype).requires_grad_(True)
+    g0, b0, a0 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    z = F.batch_norm(xq, rm, rv, g0, b0, training=True, momentum=0.1, eps=1e-5)
+    y = F.prelu(z, a0) + q(res, dtype)
+    y.backward(q(dy, dtype))
+
+    xd = to_ndhwc(x, dtype)
+    rows = ops.bn_stats_rows(xd)
+    part = torch.empty((rows, 2, c), device=DEV)
+    ops.bn_stats(xd, part)
+    mean, invstd, scale, shift = (torch.empty(c, device=DEV) for _ in range(4))
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    gd, bd, ad = gamma.to(DEV), beta.to(DEV), alpha.to(DEV)
+    count = n * sp[0] * sp[1] * sp[2]
+    ops.bn_finalize(part, rows, c, count, gd, bd, rmd, rvd, 0.1, 1e-5, mean, invstd, scale, shift)
+    yd = torch.empty_like(xd)
+    ops.bn_act_fwd(xd, yd, scale, shift, ad, to_ndhwc(res, dtype))
+    torch.cuda.synchronize()
+    t = tol(dtype)
+    assert relerr(from_ndhwc(yd), y.detach()) < t
+    assert relerr(rmd.cpu(), rm) < 1e-5 and relerr(rvd.cpu(), rv) < 1e-5
+    # backward
+    dyd = to_ndhwc(dy, dtype)
+    rrows = ops.bn_act_bwd_rows(xd)
+    rp = torch.empty((rrows, 3, c), device=DEV)
+    ops.bn_act_bwd_reduce(dyd, xd, mean, invstd, gd, bd, ad, rp)
+    dg, dbt, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty((2, c), device=DEV)
+    da = torch.empty(1, device=DEV)
+    ops.bn_act_bwd_finalize(rp, rrows, c, count, gd, invstd, dg, dbt, da, coef)
+    dxd = torch.empty_like(xd)
+    ops.bn_act_bwd_apply(dyd, xd, dxd, mean, invstd, gd, bd, ad, coef)
+    torch.cuda.synchronize()
+    assert relerr(dg.cpu(), g0.grad) < 1e-4
+    assert relerr(dbt.cpu(), b0.grad) < 1e-4
+    assert relerr(da.cpu(), a0.grad) < 1e-4
+    assert relerr(from_ndhwc(dxd), xq.grad) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k", [2, 3, 16, 32])
+def test_softmax_dice(dtype, k):
+    from oracle.unet_ref import ref_dice_loss
+    n, sp = 2, (12, 20, 24)
+    lg = rnd((n, k) + sp, 61, 3.0)
+    g = torch.Generator().manual_seed(62)
+    lab = torch.randint(0, k, (n, 1) + sp, generator=g).float()
+    lq = q(lg, dtype).requires_grad_(True)
+    loss = ref_dice_loss(lq, lab)
+    loss.backward()
+    ld = to_ndhwc(lg, dtype)
+    labd = lab.to(DEV).reshape(-1).contiguous()
+    chunks = ops.dice_chunks(ld)
+    part = torch.empty((n, chunks, 3, k), device=DEV)
+    coef = torch.empty((n, 2, k), device=DEV)
+    out = torch.empty(1, device=DEV)
+    ops.softmax_dice_fwd(ld, labd, part, coef, out)
+    dl = torch.empty_like(ld)
+    ops.softmax_dice_bwd(ld, labd, coef, 1.0, dl)
+    torch.cuda.synchronize()
+    assert abs(float(out.cpu()) - float(loss)) < 1e-6 * max(1.0, abs(float(loss)))  # loss within 1e-4 rel gate
+    assert relerr(from_ndhwc(dl), lq.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+def test_adam_sgd_match_torch():
+    n = 100003
+    p0, g = rnd((n,), 71), rnd((n,), 72, 0.1)
+    for amsgrad in (False, True):
+        pr = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pr], lr=1e-3, amsgrad=amsgrad)
+        pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        vm = torch.zeros(n, device=DEV) if amsgrad else None
+        for step in range(1, 4):
+            pr.grad = g * step
+            opt.step()
+            ops.adam_step(pd, (g * step).to(DEV), m, v, vm, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+        torch.cuda.synchronize()
+        assert float((pd.cpu() - pr.detach()).abs().max()) < 2e-7
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=1e-2, momentum=0.9)
+    pd, buf = p0.to(DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        pr.grad = g * step
+        opt.step()
+        ops.sgd_step(pd, (g * step).to(DEV), buf, 1e-2, 0.9, 0.0, step == 1)
+    torch.cuda.synchronize()
+    assert float((pd.cpu() - pr.detach()).abs().max()) < 2e-7
+
+
+def test_argmax_bit_exact_with_ties():
+    g = torch.Generator().manual_seed(81)
+    lg = torch.randint(-3, 4, (2, 7, 5, 6, 9), generator=g).float()  # many exact ties
+    ref = torch.argmax(lg, dim=1)
+    for dt in (torch.float32, torch.bfloat16):
+        ld = to_ndhwc(lg, dt)
+        for ldt in (torch.uint8, torch.int16, torch.int32):
+            lab = torch.empty((2, 5, 6, 9), dtype=ldt, device=DEV)
+            ops.argmax(ld, lab)
+            torch.cuda.synchronize()
+            assert torch.equal(lab.cpu().long(), ref)
+
+
+def test_sliding_window_ops_match_oracle():
+    from oracle.sliding_ref import ref_sliding_window_inference, window_starts
+    img = rnd((1, 1, 20, 27, 33), 91)
+    K, roi = 4, (16, 16, 16)
+    wts = rnd((K, 1, 3, 3, 3), 92)
+
+    def predictor(x):
+        return F.conv3d(x, wts, padding=1)
+
+    for overlap in (0.25, 0.5):
+        ref, cnt_ref, wins = ref_sliding_window_inference(img, roi, 4, predictor, overlap)
+        imd = img.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+        acc = torch.zeros((1, 20, 27, 33, K), device=DEV)
+        cnt = torch.zeros((20, 27, 33), device=DEV)
+        for g0 in range(0, len(wins), 4):
+            grp = wins[g0:g0 + 4]
+            wd = torch.empty((len(grp),) + roi + (1,), device=DEV)
+            ops.sw_gather(imd, 0, grp, wd)
+            pred = predictor(wd.cpu().permute(0, 4, 1, 2, 3))  # oracle predictor: isolates the data movement
+            pd = pred.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+            ops.sw_scatter_add(pd, grp, acc, cnt)
+        lab = torch.empty((20, 27, 33), dtype=torch.uint8, device=DEV)
+        ops.sw_finalize(acc, cnt, lab, write_logits=True)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt.cpu(), cnt_ref[0, 0])
+        got = acc.cpu().permute(0, 4, 1, 2, 3)
+        assert torch.equal(got, ref)  # same f32 accumulation order -> bit exact
+        assert torch.equal(lab.cpu().long(), torch.argmax(ref, 1)[0])
+
+
+def test_label_counts_and_dice_metric():
+    from oracle.metrics_ref import ref_dice_metric
+    g = torch.Generator().manual_seed(95)
+    K = 5
+    pred = torch.randint(0, K, (1, 1, 9, 10, 11), generator=g)
+    true = torch.randint(0, K - 1, (1, 1, 9, 10, 11), generator=g)  # class K-1 absent -> NaN
+    counts = torch.zeros((K, 3), dtype=torch.int64, device=DEV)
+    ops.label_counts(pred.int().to(DEV).reshape(-1), true.int().to(DEV).reshape(-1), K, counts)
+    torch.cuda.synchronize()
+    c = counts.cpu().double()
+    dice = torch.where(c[:, 2] > 0, 2 * c[:, 0] / (c[:, 1] + c[:, 2]), torch.full((K,), float("nan"), dtype=torch.double))
+    ref, _ = ref_dice_metric(pred, true, K, include_background=True)
+    assert torch.allclose(dice.float(), ref[0], equal_nan=True, atol=1e-6)
+
+
+@pytest.mark.parametrize("nearest", [False, True])
+def test_resample_matches_itk_oracle(nearest):
+    from oracle.resample_ref import ref_resample_grid, resample_size
+    rng = np.random.default_rng(7)
+    arr = rng.standard_normal((9, 11, 13)).astype(np.float32)
+    sp_in, sp_out = (0.5, 0.6, 0.7), (0.3, 0.45, 0.4)
+    size = resample_size(arr.shape[::-1], sp_in, sp_out)
+    ref = ref_resample_grid(arr, sp_in, (1, 2, 3), np.eye(3), size, sp_out, (1, 2, 3), np.eye(3), nearest)
+    m = np.zeros((3, 4))
+    for d in range(3):
+        m[d, d] = sp_out[d] / sp_in[d]
+    got = ops.resample3d(torch.from_numpy(arr).to(DEV), size[::-1], m, nearest=nearest)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-6)
+    # integer pixel type: labels
+    lab = rng.integers(0, 200, (9, 11, 13)).astype(np.uint8)
+    ref_l = ref_resample_grid(lab, sp_in, (0, 0, 0), np.eye(3), size, sp_out, (0, 0, 0), np.eye(3), nearest)
+    got_l = ops.resample3d(torch.from_numpy(lab).to(DEV), size[::-1], m, nearest=nearest)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_l.cpu().numpy(), ref_l)
+
+
+def test_normalize_intensity():
+    from oracle.metrics_ref import ref_normalize
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((2, 17, 19, 23)) * 37 + 100).astype(np.float32)
+    x[1] = 5.0  # constant channel: std 0 -> divide by 1
+    ref = ref_normalize(x)
+    got = ops.normalize_intensity_(torch.from_numpy(x.copy()).to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6)
