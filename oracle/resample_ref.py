@@ -36,7 +36,7 @@ def resample_size(size: Sequence[int], spacing: Sequence[float],
 def ref_resample_grid(arr: np.ndarray, in_spacing, in_origin, in_direction,
                       out_size, out_spacing, out_origin, out_direction,
                       nearest: bool = False, transform: Optional[np.ndarray] = None,
-                      default: float = 0.0) -> np.ndarray:
+                      default: float = 0.0, return_real: bool = False) -> np.ndarray:
     """arr [z,y,x] (or [y,x]); geometry tuples in (x,y,z) order; ``transform`` optional 4x4
     (3x3 in 2-D) homogeneous matrix mapping output-physical -> input-physical points."""
     nd = arr.ndim
@@ -82,6 +82,8 @@ def ref_resample_grid(arr: np.ndarray, in_spacing, in_origin, in_direction,
                     ix.append(lo[..., d])
             val = val + w * a[tuple(ix[::-1])]
     val = np.where(inside, val, float(default))
+    if return_real:
+        return val
     if np.issubdtype(arr.dtype, np.integer):
         info = np.iinfo(arr.dtype)
         val = np.trunc(np.clip(val, info.min, info.max))

@@ -59,10 +59,11 @@ __global__ void resample_kernel(ResampleParams p) {
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
           const int xi = (corner & 1) ? x1 : x0, yi = (corner & 2) ? y1 : y0, zi = (corner & 4) ? z1 : z0;
+          // explicit round-to-nearest mul/add: no FMA contraction, same bits as the numpy oracle
           double w = (corner & 1) ? fx : 1.0 - fx;
-          w = w * ((corner & 2) ? fy : 1.0 - fy);
-          w = w * ((corner & 4) ? fz : 1.0 - fz);
-          val = val + w * (double)src[((int64_t)zi * p.sy + yi) * p.sx + xi];
+          w = __dmul_rn(w, (corner & 2) ? fy : 1.0 - fy);
+          w = __dmul_rn(w, (corner & 4) ? fz : 1.0 - fz);
+          val = __dadd_rn(val, __dmul_rn(w, (double)src[((int64_t)zi * p.sy + yi) * p.sx + xi]));
         }
       }
     }
