@@ -1,0 +1,148 @@
+"""Sliding-window inference on device.
+
+Replaces ``monai.inferers.sliding_window_inference`` / ``SlidingWindowInferer`` as called at
+reference ``src/segmantic/seg/monai_unet.py:354-356`` (validation: roi 160^d, sw_batch 4),
+``:637-639,665`` (predict) and ``:840-842`` (ensemble: roi 96, overlap 0.5).
+
+Window schedule (host, integer arithmetic -- identical to MONAI's ``dense_patch_slices``):
+  image smaller than roi -> symmetric zero padding (half = diff // 2 low);
+  interval = roi if roi == img else max(int(roi * (1 - overlap)), 1);
+  n = ceil((img - roi) / interval) + 1 ; start_k = min(k * interval, img - roi);
+  windows enumerated with the first spatial dim slowest, groups of ``sw_batch_size``.
+Data path (device): gather kernel -> predictor -> ordered blend kernel into an f32 NDHWC
+accumulator + count map -> divide (+ fused argmax).  The blend adds windows in schedule order so
+its f32 result is bit-identical to the reference's sequential ``out[slice] += w * pred``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+from .losses import as_ndhwc
+
+
+def scan_intervals(image_size, roi, overlap) -> List[int]:
+    out = []
+    for i, r in zip(image_size, roi):
+        if r == i:
+            out.append(int(r))
+        else:
+            iv = int(r * (1 - overlap))
+            out.append(iv if iv > 0 else 1)
+    return out
+
+
+def window_starts(image_size, roi, overlap) -> List[Tuple[int, ...]]:
+    iv = scan_intervals(image_size, roi, overlap)
+    per_dim = []
+    for i, r, s in zip(image_size, roi, iv):
+        n = int(math.ceil(float(i - r) / s)) + 1
+        per_dim.append([min(k * s, i - r) for k in range(n)])
+    wins = [()]
+    for starts in per_dim:
+        wins = [w + (s,) for w in wins for s in starts]
+    return wins
+
+
+def gaussian_importance(roi, sigma_scale=0.125, device="cpu") -> torch.Tensor:
+    w = torch.ones(tuple(roi), dtype=torch.float32)
+    for d, r in enumerate(roi):
+        sigma = sigma_scale * r
+        x = torch.arange(-(r - 1) / 2.0, (r - 1) / 2.0 + 1, dtype=torch.float32)
+        g = torch.exp(x ** 2 / (-2 * sigma ** 2))
+        shp = [1] * len(roi)
+        shp[d] = r
+        w = w * g.reshape(shp)
+    mn = max(float(w[w != 0].min()), 1e-3)
+    return torch.clamp(w, min=mn).contiguous().to(device)
+
+
+class SlidingWindowResult:
+    """logits: logical [B,K,D,H,W] f32 view of the NDHWC accumulator; labels [B,1,D,H,W]."""
+
+    def __init__(self, logits, labels, count):
+        self.logits, self.labels, self.count = logits, labels, count
+
+
+def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_batch_size: int,
+                             predictor: Callable[[torch.Tensor], torch.Tensor],
+                             overlap: float = 0.25, mode: str = "constant",
+                             sigma_scale: float = 0.125, device=None,
+                             return_labels: bool = False, window_dtype: torch.dtype = torch.float32,
+                             window_range: Optional[Tuple[int, int]] = None):
+    """inputs [B,C,D,H,W] float32 on the GPU.  ``predictor`` maps [b,C,*roi] -> [b,K,*roi].
+
+    Returns logits [B,K,D,H,W] (float32), or a ``SlidingWindowResult`` when ``return_labels``.
+    ``window_range`` restricts the schedule to windows [lo, hi) (multi-GPU sharding).
+    """
+    if inputs.dim() != 5:
+        raise ValueError("sliding_window_inference expects [B,C,D,H,W]")
+    if not inputs.is_cuda:
+        raise RuntimeError("segmantic_amd sliding-window inference runs on the GPU only")
+    if not 0 <= overlap < 1:
+        raise ValueError("overlap must be >= 0 and < 1.")
+    B, Cin = inputs.shape[0], inputs.shape[1]
+    orig = list(inputs.shape[2:])
+    roi = [int(r) if r else int(o) for r, o in zip(roi_size, orig)]
+    image_size = [max(o, r) for o, r in zip(orig, roi)]
+    pad_lo = [max(r - o, 0) // 2 for o, r in zip(orig, roi)]
+    wins = window_starts(image_size, roi, overlap)
+    lo, hi = (0, len(wins)) if window_range is None else window_range
+    # window origins in un-padded image coordinates (the gather kernel zero-fills outside)
+    wins_u = [tuple(s - p for s, p in zip(w, pad_lo)) for w in wins]
+    img = inputs.float()
+    img = img.view(B, orig[0], orig[1], orig[2], 1) if Cin == 1 and img.is_contiguous() else as_ndhwc(img)
+    imp = None
+    if mode == "gaussian":
+        imp = gaussian_importance(roi, sigma_scale, inputs.device).view(-1)
+    elif mode != "constant":
+        raise ValueError(f"unsupported blend mode {mode}")
+    acc = None
+    cnt = None
+    K = None
+    outs, labs, cnts = [], [], []
+    for b in range(B):
+        for g0 in range(lo, hi, sw_batch_size):
+            grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
+            wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
+                               device=inputs.device)
+            ops.sw_gather(img, b, grp, wbuf)
+            pred = predictor(wbuf.permute(0, 4, 1, 2, 3))
+            pn = as_ndhwc(pred)
+            if acc is None:
+                K = pn.shape[4]
+                acc = torch.zeros((1, orig[0], orig[1], orig[2], K), dtype=torch.float32,
+                                  device=inputs.device)
+                cnt = torch.zeros((orig[0], orig[1], orig[2]), dtype=torch.float32,
+                                  device=inputs.device)
+            ops.sw_scatter_add(pn, grp, acc, cnt, imp)
+        if window_range is not None:
+            outs.append(acc); cnts.append(cnt); labs.append(None)
+        else:
+            lab = torch.empty((orig[0], orig[1], orig[2]),
+                              dtype=torch.uint8 if K <= 256 else torch.int32, device=inputs.device)
+            ops.sw_finalize(acc, cnt, lab, write_logits=True)
+            outs.append(acc); cnts.append(cnt); labs.append(lab)
+        acc = cnt = None
+    logits = torch.cat(outs, 0).permute(0, 4, 1, 2, 3) if B > 1 else outs[0].permute(0, 4, 1, 2, 3)
+    if not return_labels:
+        return logits
+    labels = None if labs[0] is None else torch.stack(labs).unsqueeze(1)
+    return SlidingWindowResult(logits, labels, torch.stack(cnts))
+
+
+class SlidingWindowInferer:
+    """``monai.inferers.SlidingWindowInferer`` surface (roi_size, sw_batch_size, overlap, mode)."""
+
+    def __init__(self, roi_size, sw_batch_size: int = 1, overlap: float = 0.25,
+                 mode: str = "constant", sigma_scale: float = 0.125, device=None, **_unused):
+        self.roi_size, self.sw_batch_size = roi_size, sw_batch_size
+        self.overlap, self.mode, self.sigma_scale, self.device = overlap, mode, sigma_scale, device
+
+    def __call__(self, inputs: torch.Tensor, network: Callable, return_labels: bool = False):
+        return sliding_window_inference(inputs, self.roi_size, self.sw_batch_size, network,
+                                        self.overlap, self.mode, self.sigma_scale, self.device,
+                                        return_labels=return_labels)

@@ -1,0 +1,472 @@
+"""Drop-in for ``segmantic.seg.monai_unet`` (reference ``src/segmantic/seg/monai_unet.py``).
+
+Same public names and argument meaning -- ``Net``, ``train``, ``predict`` -- but nothing below
+this module is MONAI / Lightning: the network runs on the hand-written HIP kernels of
+``libsegmi.so`` through ``UNetEngine``; the training loop, checkpoint format, early stopping
+and top-k checkpointing of Lightning (``:503-541``) are re-stated in ~100 lines of host code.
+
+``mixed_precision=True`` selects bf16 storage with f32 accumulation (the reference's
+``precision=16`` AMP, ``:533``); ``False`` selects the exact-f32 MFMA path used for parity.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from collections.abc import Sequence
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..image.labels import load_decathlon_tissuelist, load_tissue_list
+from .distributed import GradSync, broadcast_buffers, env_world, init_distributed
+from .inferers import SlidingWindowInferer, sliding_window_inference
+from .losses import DiceLoss, DiceMetric, as_ndhwc, dice_backward, dice_forward
+from .optim import make_optimizer, make_scheduler
+from .unet import UNetEngine, UNetParams
+from .utils import make_device
+
+
+class AttributeDict(dict):
+    """``hparams`` container (attribute + item access), as Lightning's ``save_hyperparameters``."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class _UNetFn(torch.autograd.Function):
+    """Bridges the engine's explicit backward into autograd for external training loops."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net):
+        ctx.net = net
+        return net._engine_for(x).forward(x, train=True).permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.net._engine
+        gd = as_ndhwc(g)
+        if gd.dtype != eng.dtype:
+            gd = gd.to(eng.dtype)
+        eng.backward(gd)      # writes p.grad (views of the flat gradient arena) directly
+        return None, None, None
+
+
+class Net(torch.nn.Module):
+    """``segmantic.seg.monai_unet.Net`` (reference ``:75-397``) on MI355X kernels."""
+
+    cache_rate: float = 1.0
+    config_preprocessing: dict = {}
+    config_augmentation: dict = {}
+    augment_intensity: bool = False
+    augment_spatial: bool = False
+    num_samples: int = 4
+    optimizer: dict = {"optimizer": "Adam", "lr": 1e-4, "momentum": 0.9, "epsilon": 1e-8,
+                       "amsgrad": False, "weight_decouple": False}
+    lr_scheduling: dict = {"scheduler": "Constant", "factor": 0.5, "patience": 10, "T_0": 50,
+                           "T_multi": 1}
+
+    def __init__(self, num_classes: int, num_channels: int = 1, spatial_dims: int = 3,
+                 spatial_size: Sequence[int] = None,
+                 channels: tuple = (16, 32, 64, 128, 256), strides: tuple = (2, 2, 2, 2),
+                 dropout: float = 0.0, act: str = "PRELU"):
+        super().__init__()
+        self.hparams = AttributeDict(num_classes=num_classes, num_channels=num_channels,
+                                     spatial_dims=spatial_dims, spatial_size=spatial_size,
+                                     channels=channels, strides=strides, dropout=dropout, act=act)
+        if str(act).upper() != "PRELU":
+            raise NotImplementedError("segmantic_amd implements act='PRELU' (the reference default)")
+        if dropout not in (0, 0.0, None):
+            raise NotImplementedError("segmantic_amd implements dropout=0.0 (the reference default)")
+        self._model = UNetParams(spatial_dims=spatial_dims, in_channels=num_channels,
+                                 out_channels=num_classes, channels=channels, strides=strides,
+                                 num_res_units=2)
+        self.spatial_size = list(spatial_size) if spatial_size else [96] * 3
+        self.loss_function = DiceLoss(to_onehot_y=True, softmax=True)
+        self.dice_metric = DiceMetric(num_classes, include_background=False)
+        self.best_val_dice = 0.0
+        self.best_val_epoch = 0.0
+        self.current_epoch = 0
+        self.validation_step_outputs: List[dict] = []
+        self.mixed_precision = False
+        self._engine: Optional[UNetEngine] = None
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._opt = None
+        self._sched = None
+        self._gsync: Optional[GradSync] = None
+        self.dataset = None
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def num_classes(self):
+        return self._model.out_channels
+
+    @property
+    def spatial_dims(self):
+        return self._model.dimensions
+
+    @property
+    def device(self):
+        return next(self._model.parameters()).device
+
+    @property
+    def compute_dtype(self):
+        return torch.bfloat16 if self.mixed_precision else torch.float32
+
+    # ------------------------------------------------------------------ engine
+    def _engine_for(self, x: Optional[torch.Tensor] = None) -> UNetEngine:
+        dev = self.device
+        if dev.type != "cuda":
+            if x is not None and x.is_cuda:
+                self.to(x.device)
+                dev = x.device
+            else:
+                raise RuntimeError(
+                    "segmantic_amd.Net computes on an MI355X only: move the module to a cuda "
+                    "device (net.to('cuda:0')).  There is no CPU execution path.")
+        if self._engine is None or self._engine.device != dev or self._engine.dtype != self.compute_dtype:
+            with torch.cuda.device(dev):
+                self._engine = UNetEngine(self._model, dev, self.compute_dtype)
+            self._opt = None
+        return self._engine
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda(): parameters leave the arena -> rebuild lazily
+        out = super()._apply(fn, *a, **k)
+        self._engine = None
+        self._opt = None
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._engine is not None:
+            self._engine.bump()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[B, C, D, H, W] float32 -> logits [B, K, D, H, W] (NDHWC storage, compute dtype)."""
+        eng = self._engine_for(x)
+        with torch.cuda.device(eng.device):
+            if self.training and torch.is_grad_enabled():
+                return _UNetFn.apply(x, self._anchor, self)
+            return eng.forward(x, train=self.training).permute(0, 4, 1, 2, 3)
+
+    # ------------------------------------------------------------------ optimisers
+    def configure_optimizers(self):
+        eng = self._engine_for()
+        self._opt = make_optimizer(self.optimizer, eng.flat, eng.flat_grad)
+        self._sched = make_scheduler(self.lr_scheduling, self._opt)
+        return [self._opt], [self._sched]
+
+    def optimizers(self):
+        if self._opt is None:
+            self.configure_optimizers()
+        return self._opt
+
+    def lr_schedulers(self):
+        if self._sched is None:
+            self.configure_optimizers()
+        return self._sched
+
+    def enable_grad_sync(self, bucket_bytes: int = 4 << 20):
+        """Data-parallel training: all-reduce the gradient arena overlapped with backward."""
+        eng = self._engine_for()
+        self._gsync = GradSync(eng.flat_grad, bucket_bytes)
+        eng.grad_hook = self._gsync.ready
+        return self._gsync
+
+    # ------------------------------------------------------------------ steps
+    def training_step(self, batch, batch_idx=0):
+        """reference ``:339-348``: forward -> zero_grad -> Dice -> backward -> optimizer.step,
+        as explicit kernel sequences (no autograd graph)."""
+        images, labels = batch["image"], batch["label"]
+        eng = self._engine_for(images)
+        with torch.cuda.device(eng.device):
+            opt = self.optimizers()
+            logits = eng.forward(images, train=True)
+            st = self.loss_function._state
+            loss = dice_forward(st, logits, labels, self.loss_function.smooth_nr,
+                                self.loss_function.smooth_dr)
+            dlogits = dice_backward(st, logits, 1.0, eng._buf("dlogits", logits.shape))
+            if self._gsync is not None:
+                self._gsync.start()
+            eng.backward(dlogits)
+            scale = 1.0
+            if self._gsync is not None:
+                self._gsync.finish()
+                scale = self._gsync.grad_scale
+            opt.step(scale)
+            eng.bump()
+        return {"loss": loss}
+
+    def validation_step(self, batch, batch_idx=0):
+        """reference ``:350-363``: sliding window roi 160^d, sw_batch 4, Dice loss + metric."""
+        images, labels = batch["image"], batch["label"]
+        roi_size = tuple(160 for _ in range(self.spatial_dims))
+        was = self.training
+        self.eval()
+        with torch.no_grad():
+            res = sliding_window_inference(images.to(self.device), roi_size, 4, self.forward,
+                                           return_labels=True, window_dtype=torch.float32)
+            loss = self.loss_function(res.logits, labels)
+            d = self.dice_metric(res.labels, labels.to(self.device).long())
+        self.train(was)
+        out = {"val_loss": loss, "val_number": images.shape[0], "dice": d}
+        self.validation_step_outputs.append(out)
+        return out
+
+    def on_validation_epoch_end(self):
+        """reference ``:365-397``"""
+        val_loss, num_items = 0.0, 0
+        for o in self.validation_step_outputs:
+            val_loss += float(o["val_loss"].sum().item())
+            num_items += o["val_number"]
+        mean_val_dice = float(self.dice_metric.aggregate().item())
+        self.dice_metric.reset()
+        mean_val_loss = val_loss / max(num_items, 1)
+        self.validation_step_outputs.clear()
+        sched = self.lr_schedulers()
+        sched.step(mean_val_loss)
+        if mean_val_dice > self.best_val_dice:
+            self.best_val_dice = mean_val_dice
+            self.best_val_epoch = self.current_epoch
+        print(f"\ncurrent epoch: {self.current_epoch} mean val dice: {mean_val_dice:.4f}"
+              f"\ncurrent mean loss: {mean_val_loss:.4f}"
+              f"\nbest mean dice: {self.best_val_dice:.4f} at epoch: {self.best_val_epoch}")
+        return {"val_dice": mean_val_dice, "val_loss": mean_val_loss}
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, path: Path, epoch: int = 0, extra: Optional[dict] = None):
+        """Lightning-compatible ``.ckpt``: ``state_dict`` keys ``_model.model.<MONAI path>`` and
+        ``hyper_parameters`` = constructor kwargs (reference ``:112, :503-509, :564-574``)."""
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
+        ckpt = {"state_dict": sd, "hyper_parameters": dict(self.hparams), "epoch": epoch,
+                "pytorch-lightning_version": "2.0.0-compatible (segmantic_amd)"}
+        if extra:
+            ckpt.update(extra)
+        torch.save(ckpt, str(path))
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides) -> "Net":
+        ckpt = torch.load(str(checkpoint_path), map_location="cpu", weights_only=False)
+        if "state_dict" not in ckpt:
+            # scripts/extract_unet.py output: bare inner-UNet state dict (keys "model....")
+            sd = {"_model." + k: v for k, v in ckpt.items()}
+            hp = {}
+        else:
+            sd, hp = ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        if "num_classes" not in hp:
+            last = [k for k in sd if k.endswith("2.1.conv.unit0.conv.bias") and k.count("submodule") == 0]
+            hp["num_classes"] = int(sd[last[0]].shape[0])
+        if "num_channels" not in hp:
+            hp["num_channels"] = int(sd["_model.model.0.conv.unit0.conv.weight"].shape[1])
+        net = cls(**hp)
+        net.load_state_dict(sd, strict=True)
+        return net
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+
+# =============================================================================================
+# train / predict
+# =============================================================================================
+def _ckpt_name(output_dir: Path, epoch: int, val_loss: float, val_dice: float) -> Path:
+    # Lightning's "{epoch}-{val_loss:.2f}-{val_dice:.4f}" -> "epoch=E-val_loss=L-val_dice=D.ckpt"
+    return Path(output_dir) / f"epoch={epoch}-val_loss={val_loss:.2f}-val_dice={val_dice:.4f}.ckpt"
+
+
+def train(
+    *,
+    datalist: Path,
+    image_dir: Path = None,
+    labels_dir: Path = None,
+    output_dir: Path,
+    checkpoint_file: Path = None,
+    num_classes: int = 0,
+    num_channels: int = 1,
+    spatial_dims: int = 3,
+    spatial_size: Sequence[int] = [],
+    preprocessing: dict = {},
+    augmentation: dict = {},
+    augment_intensity: bool = False,
+    augment_spatial: bool = False,
+    channels: tuple = (16, 32, 64, 128, 256),
+    strides: tuple = (2, 2, 2, 2),
+    dropout: float = 0.0,
+    act: str = "PRELU",
+    num_samples: int = 4,
+    optimizer=None,
+    lr_scheduling=None,
+    max_epochs: int = 600,
+    early_stop_patience: int = 50,
+    mixed_precision: bool = True,
+    cache_rate: float = 1.0,
+    gpu_ids: list = [0],
+    tissue_list: Path = None,
+) -> Net:
+    """Same keyword-only signature as the reference's ``train`` (``:400-428``): it *is* the
+    YAML/JSON config schema of ``segmantic-unet train-config``."""
+    from .dataset import PairedDataSet
+    from .trainer import fit
+
+    if optimizer is None:
+        optimizer = dict(Net.optimizer)
+    if lr_scheduling is None:
+        lr_scheduling = dict(Net.lr_scheduling)
+
+    if checkpoint_file and Path(checkpoint_file).exists():
+        net = Net.load_from_checkpoint(f"{checkpoint_file}", map_location="cpu")
+        net.best_val_dice = 0.0
+    else:
+        if num_classes > 0 and tissue_list:
+            raise ValueError("'num_classes' and 'tissue_list' are redundant. Prefer 'num_classes'.")
+        if num_classes <= 0:
+            if tissue_list:
+                tissue_dict = load_tissue_list(tissue_list)
+            else:
+                tissue_dict = load_decathlon_tissuelist(Path(datalist))
+            num_classes = max(tissue_dict.values()) + 1
+            if len(tissue_dict) != num_classes:
+                raise ValueError("Expecting contiguous labels in range [0,N-1]")
+        if num_classes <= 1:
+            raise ValueError("'num_classes' is expected to be > 1")
+        net = Net(spatial_dims=spatial_dims, num_channels=num_channels, num_classes=num_classes,
+                  spatial_size=spatial_size, channels=channels, strides=strides, dropout=dropout,
+                  act=act)
+    if image_dir and labels_dir:
+        net.dataset = PairedDataSet(image_dir=image_dir, labels_dir=labels_dir)
+    elif datalist:
+        net.dataset = PairedDataSet.load_from_json(datalist)
+    else:
+        raise ValueError("Either provide a dataset file, or an image_dir, labels_dir pair.")
+    if preprocessing or augmentation:
+        raise NotImplementedError(
+            "segmantic_amd: MONAI-bundle 'preprocessing' / 'augmentation' dictionaries need MONAI's "
+            "ConfigParser; leave them empty to use the built-in default pipeline")
+    net.config_preprocessing = preprocessing
+    net.config_augmentation = augmentation
+    net.augment_intensity = augment_intensity
+    net.augment_spatial = augment_spatial
+    net.num_samples = num_samples
+    net.optimizer = optimizer
+    net.lr_scheduling = lr_scheduling
+    net.cache_rate = cache_rate
+    net.mixed_precision = bool(mixed_precision)
+
+    output_dir = Path(output_dir)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    (output_dir / "Dataset.json").write_text(net.dataset.dump_dataset())
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "segmantic_amd.train needs an MI355X: torch.cuda.is_available() is False and there "
+            "is no CPU execution path (the reference's gpu_ids=[] CPU mode is served by the "
+            "reference itself)")
+    fit(net, output_dir=output_dir, max_epochs=max_epochs, early_stop_patience=early_stop_patience,
+        gpu_ids=gpu_ids, ckpt_name=_ckpt_name)
+    print(f"train completed, best_metric: {net.best_val_dice:.4f} at epoch {net.best_val_epoch}")
+    return net
+
+
+def predict(
+    model_file: Path,
+    test_images: List[Path],
+    test_labels: Optional[List[Path]] = None,
+    output_dir: Path = None,
+    tissue_dict: Dict[str, int] = None,
+    channels: tuple = (16, 32, 64, 128, 256),
+    strides: tuple = (2, 2, 2, 2),
+    dropout: float = 0.0,
+    spacing: Sequence[float] = [],
+    gpu_ids: List[int] = [],
+) -> None:
+    """reference ``:551-725``: load checkpoint, sliding-window inference per volume, invert the
+    pre-processing on the logits, argmax, save, Dice / confusion statistics when labels exist."""
+    from .pipeline import PredictPipeline
+
+    model_file = Path(model_file)
+    settings_json = model_file.with_suffix(".json")
+    if settings_json.exists():
+        print(f"WARNING: Loading legacy model settings from {settings_json}")
+        settings = json.loads(settings_json.read_text())
+        net = Net.load_from_checkpoint(f"{model_file}", **settings)
+    else:
+        net = Net.load_from_checkpoint(f"{model_file}", channels=channels, strides=strides,
+                                       dropout=dropout)
+    num_classes = net.num_classes
+    net.freeze()
+    net.eval()
+    device = make_device(gpu_ids)
+    if device.type != "cuda":
+        raise RuntimeError("segmantic_amd.predict needs an MI355X (no CPU execution path)")
+    net.to(device)
+
+    use_labels = bool(test_labels) and len(test_images) == len(test_labels)
+    pipe = PredictPipeline(device=device, spacing=spacing, with_label=use_labels)
+    if output_dir:
+        os.makedirs(output_dir, exist_ok=True)
+        output_dir = Path(output_dir)
+    inferer = SlidingWindowInferer(roi_size=net.spatial_size, sw_batch_size=4, device=device)
+    dice_metric = DiceMetric(num_classes, include_background=False)
+
+    tissue_names = [f"{i}" for i in range(num_classes)]
+    if tissue_dict:
+        for name, idx in tissue_dict.items():
+            if 0 <= idx < num_classes:
+                tissue_names[idx] = name
+
+    def print_table(header, vals, indent="\t"):
+        print(indent + "\t".join(header).expandtabs(30))
+        print(indent + "\t".join(f"{x}" for x in vals).expandtabs(30))
+
+    all_mean_dice = []
+    class_dice_sum, class_dice_cnt = None, None
+    with torch.no_grad():
+        for i, img_path in enumerate(test_images):
+            item = pipe.load(img_path, test_labels[i] if use_labels else None)
+            val_pred = inferer(item["image"][None], net)             # [1,K,D,H,W] f32 logits
+            label_vol = pipe.invert_and_discretize(val_pred[0], item)
+            if output_dir:
+                pipe.save(label_vol, item, output_dir)
+            if use_labels:
+                pred_lab = _argmax_labels(val_pred)
+                d = dice_metric(pred_lab, item["label"][None].long())
+                dn = d.cpu().numpy()
+                print("Mean Dice: ", np.nanmean(dn))
+                print("Class Dice:")
+                print_table(tissue_names[1:], np.squeeze(dn))
+                all_mean_dice.append(float(dice_metric.aggregate().item()))
+                dz = np.nan_to_num(dn[0], nan=0.0)
+                ok = (~np.isnan(dn[0])).astype(np.float64)
+                class_dice_sum = dz if class_dice_sum is None else class_dice_sum + dz
+                class_dice_cnt = ok if class_dice_cnt is None else class_dice_cnt + ok
+        if output_dir is None:
+            print("No output path specified, dice scores won't be saved.")
+        else:
+            np.savetxt(output_dir / f"mean_dice_{model_file.stem}_generalized_score.txt",
+                       all_mean_dice, delimiter=",")
+        if use_labels:
+            print("*" * 80)
+            print("Total Mean Dice: ", float(dice_metric.aggregate().item()))
+            print("Total Class Dice:")
+            print_table(tissue_names[1:], class_dice_sum / np.maximum(class_dice_cnt, 1))
+
+
+def _argmax_labels(logits: torch.Tensor) -> torch.Tensor:
+    """[B,K,D,H,W] -> [B,1,D,H,W] int32 via the HIP argmax kernel (first max wins)."""
+    lg = as_ndhwc(logits)
+    lab = torch.empty(lg.shape[:4], dtype=torch.int32, device=lg.device)
+    ops.argmax(lg, lab)
+    return lab.unsqueeze(1)

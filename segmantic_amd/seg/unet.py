@@ -1,0 +1,633 @@
+"""3D residual UNet on the HIP kernels of libsegmi: parameter container + execution engine.
+
+Mirrors the network the reference builds at ``src/segmantic/seg/monai_unet.py:114-124``
+(``monai.networks.nets.UNet(..., num_res_units=2, norm=Norm.BATCH, act=act)``):
+
+* ``UNetParams`` is a pure parameter container whose ``state_dict()`` keys/shapes are MONAI's
+  (``model.0.conv.unit0.conv.weight`` ...; 148 tensors for the default 5-level net) so that
+  reference checkpoints load unchanged.
+* ``UNetEngine`` owns the MI355X execution plan: NDHWC activations, concat-by-offset skip
+  buffers, fused conv epilogues (bias + BN statistics in training; folded BN + PReLU +
+  residual in eval), explicit hand-scheduled backward (dgrad via the conv / transposed-conv
+  kernels with transformed weight packs, MFMA wgrad, two-pass BN/PReLU backward), one flat f32
+  parameter arena and one flat gradient arena (fused optimiser, bucketed all-reduce).
+
+No MONAI, no torch.nn compute ops, no autograd graph inside the network: every FLOP runs in a
+hand-written gfx950 kernel reached through the C-ABI.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+# =============================================================================================
+# parameter container (MONAI key layout)
+# =============================================================================================
+class _Box(nn.Module):
+    """Name-space node: holds children / parameters, computes nothing."""
+
+
+def _conv_params(cin: int, cout: int, k: int, dims: int, transposed: bool) -> _Box:
+    m = _Box()
+    shape = ((cin, cout) if transposed else (cout, cin)) + (k,) * dims
+    w = torch.empty(shape)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # torch's default conv init
+    fan_in = shape[1] * k ** dims                         # torch: weight.size(1) * receptive
+    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+    b = torch.empty(cout).uniform_(-bound, bound)
+    m.weight = nn.Parameter(w)
+    m.bias = nn.Parameter(b)
+    return m
+
+
+def _adn_params(ch: int) -> _Box:
+    adn = _Box()
+    n = _Box()
+    n.weight = nn.Parameter(torch.ones(ch))
+    n.bias = nn.Parameter(torch.zeros(ch))
+    n.register_buffer("running_mean", torch.zeros(ch))
+    n.register_buffer("running_var", torch.ones(ch))
+    n.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+    a = _Box()
+    a.weight = nn.Parameter(torch.full((1,), 0.25))
+    adn.add_module("N", n)
+    adn.add_module("A", a)
+    return adn
+
+
+def _convolution_params(cin, cout, k, dims, conv_only=False, transposed=False) -> _Box:
+    m = _Box()
+    m.add_module("conv", _conv_params(cin, cout, k, dims, transposed))
+    if not conv_only:
+        m.add_module("adn", _adn_params(cout))
+    return m
+
+
+def _residual_unit_params(cin, cout, stride, k, dims, subunits, last_conv_only=False) -> _Box:
+    m = _Box()
+    conv = _Box()
+    sc = cin
+    for su in range(max(1, subunits)):
+        conv_only = last_conv_only and su == max(1, subunits) - 1
+        conv.add_module(f"unit{su:d}", _convolution_params(sc, cout, k, dims, conv_only))
+        sc = cout
+    m.add_module("conv", conv)
+    if stride != 1 or cin != cout:
+        rk = k if stride != 1 else 1
+        m.add_module("residual", _conv_params(cin, cout, rk, dims, False))
+    return m
+
+
+class UNetParams(nn.Module):
+    """Parameter container with MONAI ``UNet`` attribute names (``.model`` Sequential tree)."""
+
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int,
+                 channels: Sequence[int], strides: Sequence[int], num_res_units: int = 2,
+                 kernel_size: int = 3):
+        super().__init__()
+        if len(channels) < 2:
+            raise ValueError("the length of `channels` should be no less than 2.")
+        if len(strides) < len(channels) - 1:
+            raise ValueError("the length of `strides` should equal to `len(channels) - 1`.")
+        if num_res_units < 1:
+            raise ValueError("segmantic builds its UNet with num_res_units=2")
+        self.dimensions = spatial_dims
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.channels = tuple(int(c) for c in channels)
+        self.strides = tuple(int(s) for s in strides)
+        d, k, nr = spatial_dims, kernel_size, num_res_units
+
+        def block(inc, outc, chs, sts, is_top):
+            c, s = chs[0], sts[0]
+            seq = _Box()
+            if len(chs) > 2:
+                sub = block(c, c, chs[1:], sts[1:], False)
+                upc = c * 2
+            else:
+                sub = _residual_unit_params(c, chs[1], 1, k, d, nr)
+                upc = c + chs[1]
+            skip = _Box()
+            skip.add_module("submodule", sub)
+            up = _Box()
+            up.add_module("0", _convolution_params(upc, outc, k, d, transposed=True))
+            up.add_module("1", _residual_unit_params(outc, outc, 1, k, d, 1, last_conv_only=is_top))
+            seq.add_module("0", _residual_unit_params(inc, c, s, k, d, nr))
+            seq.add_module("1", skip)
+            seq.add_module("2", up)
+            return seq
+
+        self.add_module("model", block(in_channels, out_channels, list(self.channels),
+                                       list(self.strides), True))
+
+
+# =============================================================================================
+# execution engine
+# =============================================================================================
+class _Conv:
+    """One (transposed) convolution: parameter views + cached weight packs."""
+
+    def __init__(self, eng: "UNetEngine", prefix: str, cin, cout, k, stride, transposed=False):
+        self.eng, self.prefix = eng, prefix
+        self.cin, self.cout, self.k, self.stride, self.transposed = cin, cout, k, stride, transposed
+        self.w = eng.param(prefix + ".weight")
+        self.b = eng.param(prefix + ".bias")
+        self.gw = eng.grad(prefix + ".weight")
+        self.gb = eng.grad(prefix + ".bias")
+        self._packs: Dict[tuple, Tuple[int, Optional[torch.Tensor]]] = {}
+        self._fold: Dict[str, tuple] = {}
+
+    @property
+    def mfma(self) -> bool:
+        return ops.mfma_ok(self.cin, self.cout)
+
+    def _pack(self, tag, kind, cin_k, cout_k, k, scale=None):
+        if not self.mfma:
+            return None
+        key = (tag, self.eng.dtype)
+        ver = self.eng.weights_version
+        hit = self._packs.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        buf = hit[1] if hit is not None else None
+        buf = ops.wpack(self.eng.dtype, kind, self.w, cin_k, cout_k, k, scale=scale, out=buf)
+        self._packs[key] = (ver, buf)
+        return buf
+
+    # forward operand
+    def fwd_pack(self):
+        if self.transposed:
+            return self._pack("fwd", 2, self.cin, self.cout, 3)
+        return self._pack("fwd", 0, self.cin, self.cout, self.k)
+
+    # input-gradient operand (the kernel that consumes it sees cin_k = cout, cout_k = cin)
+    def dgrad_pack(self):
+        if self.transposed:   # dgrad of convT = stride-2 conv over dy with the weight as is
+            return self._pack("dgrad", 0, self.cout, self.cin, 3)
+        if self.stride == 2:  # dgrad of a stride-2 conv = transposed-conv kernel, weight as is
+            return self._pack("dgrad", 2, self.cout, self.cin, 3)
+        return self._pack("dgrad", 1, self.cout, self.cin, self.k)
+
+    # eval mode: BatchNorm folded into the weights (scale) and bias
+    def folded(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]):
+        ver = self.eng.weights_version
+        hit = self._fold.get("f")
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2], hit[3]
+        if scale is None:
+            bias, wsrc, pack = self.b, self.w, self.fwd_pack()
+        else:
+            bias = torch.addcmul(shift, self.b, scale)  # b*scale + shift  (C-element prep)
+            if self.mfma:
+                kind = 2 if self.transposed else 0
+                pack = ops.wpack(self.eng.dtype, kind, self.w, self.cin, self.cout,
+                                 3 if self.transposed else self.k, scale=scale)
+                wsrc = None
+            else:
+                pack = None
+                shp = [1] * self.w.dim()
+                shp[1 if self.transposed else 0] = self.cout
+                wsrc = (self.w * scale.view(shp)).contiguous()
+        self._fold["f"] = (ver, pack, wsrc, bias)
+        return pack, wsrc, bias
+
+
+class _BN:
+    def __init__(self, eng: "UNetEngine", prefix: str, c: int):
+        self.eng, self.prefix, self.c = eng, prefix, c
+        self.gamma = eng.param(prefix + ".N.weight")
+        self.beta = eng.param(prefix + ".N.bias")
+        self.alpha = eng.param(prefix + ".A.weight")
+        self.g_gamma = eng.grad(prefix + ".N.weight")
+        self.g_beta = eng.grad(prefix + ".N.bias")
+        self.g_alpha = eng.grad(prefix + ".A.weight")
+        self.rm = eng.buffer(prefix + ".N.running_mean")
+        self.rv = eng.buffer(prefix + ".N.running_var")
+        self.nbt = eng.buffer(prefix + ".N.num_batches_tracked")
+        dev = eng.device
+        self.mean = torch.empty(c, device=dev)
+        self.invstd = torch.empty(c, device=dev)
+        self.scale = torch.empty(c, device=dev)
+        self.shift = torch.empty(c, device=dev)
+        self.coef = torch.empty((2, c), device=dev)
+        self._eval: Optional[tuple] = None
+
+    def eval_affine(self):
+        ver = self.eng.weights_version
+        if self._eval is None or self._eval[0] != ver:
+            sc = torch.empty(self.c, device=self.eng.device)
+            sh = torch.empty(self.c, device=self.eng.device)
+            ops.bn_eval_affine(self.gamma, self.beta, self.rm, self.rv, self.eng.eps, sc, sh)
+            self._eval = (ver, sc, sh)
+        return self._eval[1], self._eval[2]
+
+
+class UNetEngine:
+    """Execution plan for one ``UNetParams`` on one MI355X."""
+
+    eps = 1e-5
+    momentum = 0.1
+
+    def __init__(self, params: UNetParams, device: torch.device, dtype: torch.dtype):
+        if params.dimensions != 3:
+            raise NotImplementedError(
+                "segmantic_amd: the HIP path implements spatial_dims=3 (2-D is on the roadmap, "
+                "SURVEY.md section 8f N4)")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("compute dtype must be float32 or bfloat16")
+        if any(s not in (1, 2) for s in params.strides):
+            raise NotImplementedError("segmantic_amd: strides must be 1 or 2")
+        self.net = params
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.weights_version = 0
+        self.training = True
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self._saved: Dict[str, torch.Tensor] = {}
+        self._build_arena()
+        self._build_plan()
+
+    # ------------------------------------------------------------------ arenas
+    def _build_arena(self):
+        named = list(self.net.named_parameters())
+        total = sum(p.numel() for _, p in named)
+        self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._pviews: Dict[str, torch.Tensor] = {}
+        self._gviews: Dict[str, torch.Tensor] = {}
+        self.param_offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, p in named:
+            n = p.numel()
+            view = self.flat[off:off + n].view(p.shape)
+            view.copy_(p.data.to(self.device, torch.float32))
+            p.data = view                      # nn.Parameter now aliases the arena
+            g = self.flat_grad[off:off + n].view(p.shape)
+            p.grad = g
+            self._pviews[name] = view
+            self._gviews[name] = g
+            self.param_offsets[name] = (off, n)
+            off += n
+        self._bviews: Dict[str, torch.Tensor] = {}
+        for name, b in self.net.named_buffers():
+            b.data = b.data.to(self.device)
+            self._bviews[name] = b.data
+        self.num_params = total
+
+    def rebind(self):
+        """Re-alias parameters after an external ``.to()`` / ``load_state_dict`` replaced data."""
+        for name, p in self.net.named_parameters():
+            view = self._pviews[name]
+            if p.data.data_ptr() != view.data_ptr():
+                view.copy_(p.data.to(self.device, torch.float32))
+                p.data = view
+            p.grad = self._gviews[name]
+        for name, b in self.net.named_buffers():
+            tgt = self._bviews[name]
+            if b.data.data_ptr() != tgt.data_ptr():
+                tgt.copy_(b.data.to(self.device))
+                b.data = tgt
+        self.weights_version += 1
+
+    def param(self, key):
+        return self._pviews["model." + key]
+
+    def grad(self, key):
+        return self._gviews["model." + key]
+
+    def buffer(self, key):
+        return self._bviews["model." + key]
+
+    # ------------------------------------------------------------------ plan
+    def _build_plan(self):
+        chs, sts = list(self.net.channels), list(self.net.strides)
+        self.levels = self._make_level("", self.net.in_channels, self.net.out_channels, chs, sts, True)
+
+    def _make_ru(self, prefix, cin, cout, stride, subunits, last_conv_only=False):
+        units = []
+        sc, ss = cin, stride
+        for su in range(subunits):
+            conv_only = last_conv_only and su == subunits - 1
+            conv = _Conv(self, f"{prefix}.conv.unit{su}.conv", sc, cout, 3, ss)
+            bn = None if conv_only else _BN(self, f"{prefix}.conv.unit{su}.adn", cout)
+            units.append((conv, bn))
+            sc, ss = cout, 1
+        res = None
+        if stride != 1 or cin != cout:
+            res = _Conv(self, f"{prefix}.residual", cin, cout, 3 if stride != 1 else 1, stride)
+        return {"prefix": prefix, "units": units, "res": res, "cin": cin, "cout": cout,
+                "stride": stride}
+
+    def _make_level(self, prefix, inc, outc, chs, sts, is_top):
+        p = prefix  # e.g. "" , "1.submodule." ...
+        c, s = chs[0], sts[0]
+        lvl = {"prefix": p, "c": c, "stride": s, "is_top": is_top, "inc": inc, "outc": outc}
+        lvl["down"] = self._make_ru(p + "0", inc, c, s, 2)
+        if len(chs) > 2:
+            lvl["sub"] = self._make_level(p + "1.submodule.", c, c, chs[1:], sts[1:], False)
+            lvl["bottom"] = None
+            upc = 2 * c
+            lvl["subc"] = c
+        else:
+            lvl["sub"] = None
+            lvl["bottom"] = self._make_ru(p + "1.submodule", c, chs[1], 1, 2)
+            upc = c + chs[1]
+            lvl["subc"] = chs[1]
+        lvl["upc"] = upc
+        lvl["upconv"] = _Conv(self, p + "2.0.conv", upc, outc, 3, s, transposed=True)
+        lvl["upbn"] = _BN(self, p + "2.0.adn", outc)
+        lvl["upru"] = self._make_ru(p + "2.1", outc, outc, 1, 1, last_conv_only=is_top)
+        if s != 2:
+            raise NotImplementedError("segmantic_amd: the up path implements stride-2 levels")
+        return lvl
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype=None) -> torch.Tensor:
+        dtype = dtype or self.dtype
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def _scratch_buf(self, name, nbytes) -> torch.Tensor:
+        t = self._scratch.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty((int(nbytes * 1.25) // 256 + 2) * 256, dtype=torch.uint8,
+                            device=self.device)
+            self._scratch[name] = t
+        return t
+
+    def _fstat(self, rows, c) -> torch.Tensor:
+        return self._scratch_buf("stats", rows * 3 * c * 4).view(torch.float32)
+
+    @staticmethod
+    def _down_shape(shape, stride):
+        n, d, h, w, _ = shape
+        f = lambda v: (v + 2 - 3) // stride + 1
+        return (n, f(d), f(h), f(w))
+
+    # ------------------------------------------------------------------ primitive steps
+    def _conv_train(self, conv: _Conv, x, y, bn: Optional[_BN]):
+        """raw conv (+bias) with fused statistics, then finalize into bn.*"""
+        stats = None
+        rows = 0
+        if bn is not None:
+            rows = (ops.convT3d_stats_rows(x, y) if conv.transposed
+                    else ops.conv3d_stats_rows(x, y, conv.k, conv.stride))
+            stats = self._fstat(rows, conv.cout)
+        if conv.transposed:
+            ops.convT3d_fwd(x, y, conv.fwd_pack(), conv.w, conv.b, stats=stats)
+        else:
+            ops.conv3d_fwd(x, y, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
+                           stats=stats)
+        if bn is not None:
+            count = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
+            ops.bn_finalize(stats, rows, conv.cout, count, bn.gamma, bn.beta, bn.rm, bn.rv,
+                            self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
+            bn.nbt += 1
+
+    def _wgrad(self, conv: _Conv, x, dy):
+        """dW, db of `conv` given its forward input x and output gradient dy."""
+        if conv.transposed:
+            # dW_T[ci][co][tap]: stride-2 conv wgrad with x := dy (fine grid), dy := x (coarse)
+            nbytes = ops.conv3d_wgrad_workspace(dy, x, 3, 2)
+            ws = self._scratch_buf("wgrad", nbytes)
+            ops.conv3d_wgrad(dy, x, conv.gw, None, 3, 2, ws)
+            ops.bias_grad(dy, conv.gb, ws)
+        else:
+            nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
+            ws = self._scratch_buf("wgrad", nbytes)
+            ops.conv3d_wgrad(x, dy, conv.gw, conv.gb, conv.k, conv.stride, ws)
+
+    def _dgrad(self, conv: _Conv, dy, dx, residual=None):
+        """dx = dgrad(conv, dy) (+ residual)."""
+        if conv.transposed:
+            ops.conv3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, 0, None, 3, 2, residual=residual)
+        elif conv.stride == 2:
+            ops.convT3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, None, residual=residual)
+        else:
+            ops.conv3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, 1, None, conv.k, 1,
+                           residual=residual)
+
+    def _bn_bwd(self, bn: _BN, dy, x_raw, dx):
+        rows = ops.bn_act_bwd_rows(x_raw)
+        part = self._fstat(rows, bn.c)
+        count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
+        ops.bn_act_bwd_reduce(dy, x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part)
+        ops.bn_act_bwd_finalize(part, rows, bn.c, count, bn.gamma, bn.invstd, bn.g_gamma,
+                                bn.g_beta, bn.g_alpha, bn.coef)
+        ops.bn_act_bwd_apply(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
+                             bn.coef)
+
+    # ------------------------------------------------------------------ residual unit
+    def _ru_fwd_train(self, ru, x, out):
+        pre = ru["prefix"]
+        n, d, h, w = self._down_shape(x.shape, ru["stride"])
+        cur = x
+        nun = len(ru["units"])
+        saved = {"x": x}
+        # residual branch first, straight into `out` (then read back as the epilogue residual)
+        if ru["res"] is not None:
+            rc = ru["res"]
+            ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
+            resid = out
+        else:
+            resid = x
+        for i, (conv, bn) in enumerate(ru["units"]):
+            last = i == nun - 1
+            if bn is None:
+                # conv-only last unit (top of the net): out = conv(cur) + residual
+                ops.conv3d_fwd(cur, out, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
+                               residual=resid)
+                saved[f"in{i}"] = cur
+                break
+            r = self._buf(f"{pre}.r{i}", (n, d, h, w, conv.cout))
+            self._conv_train(conv, cur, r, bn)
+            saved[f"in{i}"] = cur
+            saved[f"r{i}"] = r
+            if last:
+                ops.bn_act_fwd(r, out, bn.scale, bn.shift, bn.alpha, residual=resid)
+            else:
+                a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
+                ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha)
+                cur = a
+        self._saved[pre] = saved
+
+    def _ru_bwd(self, ru, dout, dx=None, extra=None):
+        """Backward of a residual unit.  dout: grad of its output.  If dx is given it receives
+        the input gradient (+ `extra`, an additional gradient flowing into the same input)."""
+        pre = ru["prefix"]
+        sv = self._saved[pre]
+        x = sv["x"]
+        nun = len(ru["units"])
+        g = dout            # gradient flowing back through the conv branch
+        for i in range(nun - 1, -1, -1):
+            conv, bn = ru["units"][i]
+            xin = sv[f"in{i}"]
+            if bn is not None:
+                r = sv[f"r{i}"]
+                dr = self._buf(f"{pre}.dr{i}", r.shape)
+                self._bn_bwd(bn, g, r, dr)
+            else:
+                dr = g
+            self._wgrad(conv, xin, dr)
+            if i > 0:
+                da = self._buf(f"{pre}.da{i - 1}", xin.shape)
+                self._dgrad(conv, dr, da)
+                g = da
+            else:
+                first_dr = dr
+        rc = ru["res"]
+        if rc is not None:
+            self._wgrad(rc, x, dout)
+        # every parameter gradient of this unit (and of everything after it in the arena) is final
+        self._grads_ready(self.param_offsets[f"model.{pre}.conv.unit0.conv.weight"][0])
+        if dx is None:
+            return
+        conv0 = ru["units"][0][0]
+        if rc is not None:
+            self._dgrad(rc, dout, dx, residual=extra)
+            self._dgrad(conv0, first_dr, dx, residual=dx)
+        else:
+            # identity residual: dx = dgrad(conv0) + dout (+ extra)
+            if extra is not None:
+                ops.add(dout, extra, dx)
+                self._dgrad(conv0, first_dr, dx, residual=dx)
+            else:
+                self._dgrad(conv0, first_dr, dx, residual=dout)
+
+    def _ru_fwd_eval(self, ru, x, out):
+        pre = ru["prefix"]
+        n, d, h, w = self._down_shape(x.shape, ru["stride"])
+        if ru["res"] is not None:
+            rc = ru["res"]
+            ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
+            resid = out
+        else:
+            resid = x
+        cur = x
+        nun = len(ru["units"])
+        for i, (conv, bn) in enumerate(ru["units"]):
+            last = i == nun - 1
+            if bn is None:
+                ops.conv3d_fwd(cur, out, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
+                               residual=resid)
+                break
+            sc, sh = bn.eval_affine()
+            pack, wsrc, bias = conv.folded(sc, sh)
+            dst = out if last else self._buf(f"{pre}.ea{i}", (n, d, h, w, conv.cout))
+            ops.conv3d_fwd(cur, dst, pack, wsrc, 0, bias, conv.k, conv.stride,
+                           prelu_alpha=bn.alpha, residual=resid if last else None)
+            cur = dst
+
+    # ------------------------------------------------------------------ levels
+    def _level_fwd(self, lvl, x, out, train: bool):
+        p = lvl["prefix"]
+        n, d, h, w = self._down_shape(x.shape, lvl["stride"])
+        c, upc, subc = lvl["c"], lvl["upc"], lvl["subc"]
+        tag = "t" if train else "e"
+        cat = self._buf(f"{p}cat.{tag}", (n, d, h, w, upc))
+        down_out = cat[..., :c]
+        sub_out = cat[..., c:]
+        ru_fwd = self._ru_fwd_train if train else self._ru_fwd_eval
+        ru_fwd(lvl["down"], x, down_out)
+        if lvl["sub"] is not None:
+            self._level_fwd(lvl["sub"], down_out, sub_out, train)
+        else:
+            ru_fwd(lvl["bottom"], down_out, sub_out)
+        up, ubn = lvl["upconv"], lvl["upbn"]
+        oshape = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], lvl["outc"])
+        au = self._buf(f"{p}au.{tag}", oshape)
+        if train:
+            u = self._buf(f"{p}u", oshape)
+            self._conv_train(up, cat, u, ubn)
+            ops.bn_act_fwd(u, au, ubn.scale, ubn.shift, ubn.alpha)
+            self._saved[p + "up"] = {"cat": cat, "u": u, "au": au}
+            self._ru_fwd_train(lvl["upru"], au, out)
+        else:
+            sc, sh = ubn.eval_affine()
+            pack, wsrc, bias = up.folded(sc, sh)
+            ops.convT3d_fwd(cat, au, pack, wsrc, bias, prelu_alpha=ubn.alpha)
+            self._ru_fwd_eval(lvl["upru"], au, out)
+
+    def _level_bwd(self, lvl, dout, dx=None, extra=None):
+        p = lvl["prefix"]
+        sv = self._saved[p + "up"]
+        cat, u, au = sv["cat"], sv["u"], sv["au"]
+        c = lvl["c"]
+        dau = self._buf(f"{p}dau", au.shape)
+        self._ru_bwd(lvl["upru"], dout, dx=dau)
+        du = self._buf(f"{p}du", u.shape)
+        self._bn_bwd(lvl["upbn"], dau, u, du)
+        up = lvl["upconv"]
+        self._wgrad(up, cat, du)
+        self._grads_ready(self.param_offsets[f"model.{p}2.0.conv.weight"][0])
+        dcat = self._buf(f"{p}dcat", cat.shape)
+        self._dgrad(up, du, dcat)
+        d_down, d_sub = dcat[..., :c], dcat[..., c:]
+        dsum = self._buf(f"{p}ddown", (cat.shape[0], cat.shape[1], cat.shape[2], cat.shape[3], c))
+        if lvl["sub"] is not None:
+            self._level_bwd(lvl["sub"], d_sub, dx=dsum, extra=d_down)
+        else:
+            self._ru_bwd(lvl["bottom"], d_sub, dx=dsum, extra=d_down)
+        self._ru_bwd(lvl["down"], dsum, dx=dx, extra=extra)
+
+    # ------------------------------------------------------------------ public API
+    def _prep_input(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [N, C, D, H, W] float32 (reference layout) -> NDHWC compute-dtype tensor."""
+        if x.dim() != 5 or x.shape[1] != self.net.in_channels:
+            raise ValueError(f"expected input [N,{self.net.in_channels},D,H,W], got {tuple(x.shape)}")
+        total_stride = 1
+        for s in self.net.strides[:len(self.net.channels) - 1]:
+            total_stride *= s
+        for s in x.shape[2:]:
+            if s % total_stride != 0:
+                # the reference fails here too (torch.cat of mismatching skip tensors)
+                raise ValueError(f"spatial extent {s} is not divisible by the network's total "
+                                 f"stride {total_stride}")
+        x = x.to(self.device)
+        n, c, d, h, w = x.shape
+        xin = self._buf("input", (n, d, h, w, c))
+        if c == 1 and x.dtype == torch.float32 and x.is_contiguous():
+            src = x.view(n, d, h, w, 1)
+            if self.dtype == torch.float32:
+                return src
+            ops.cast_copy(src, xin)
+            return xin
+        ops.nchw_to_ndhwc(x.float().contiguous(), xin)
+        return xin
+
+    def forward(self, x: torch.Tensor, train: Optional[bool] = None) -> torch.Tensor:
+        """[N,C,D,H,W] f32 -> logits NDHWC tensor [N,D,H,W,K] (compute dtype)."""
+        train = self.training if train is None else train
+        xin = self._prep_input(x)
+        n, d, h, w, _ = xin.shape
+        logits = self._buf("logits." + ("t" if train else "e"), (n, d, h, w, self.net.out_channels))
+        if train:
+            self._saved.clear()
+        self._level_fwd(self.levels, xin, logits, train)
+        return logits
+
+    def backward(self, dlogits: torch.Tensor) -> None:
+        """dlogits NDHWC (compute dtype).  Fills the flat gradient arena (overwrites)."""
+        if not self._saved:
+            raise RuntimeError("backward() needs a preceding training-mode forward()")
+        self._level_bwd(self.levels, dlogits)
+
+    grad_hook = None  # callable(lo_offset): gradients at arena offsets >= lo are final
+
+    def _grads_ready(self, lo: int):
+        if self.grad_hook is not None:
+            self.grad_hook(lo)
+
+    def bump(self):
+        """Call after the parameters changed (optimiser step, load_state_dict)."""
+        self.weights_version += 1
