@@ -58,24 +58,27 @@ def test_train_step_parity_f32(cfg):
     net.to(DEV).train()
     net.mixed_precision = False
     eng = net._engine_for()
-    logits = eng.forward(img.to(DEV), train=True)
-    got = logits.float().cpu().permute(0, 4, 1, 2, 3)
-    assert rel(got, out_ref.detach()) < 2e-4           # gate: 1e-3 relative
     res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
     torch.cuda.synchronize()
+    got = eng._bufs["logits.t"].float().cpu().permute(0, 4, 1, 2, 3)
+    assert rel(got, out_ref.detach()) < 2e-4           # gate: 1e-3 relative
     loss = float(res["loss"].cpu())
-    assert abs(loss - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
-    # gradients (flat arena views) -- compared before they are overwritten
-    worst = 0.0
+    assert abs(loss - float(loss_ref.detach())) < 1e-4 * abs(float(loss_ref.detach()))
+    # gradients (flat arena views).  Conv biases in front of a BatchNorm have an exactly-zero
+    # gradient in exact arithmetic (pure rounding noise in both implementations), hence the
+    # absolute floor relative to the largest gradient of the network.
+    gmax = max(float(g.abs().max()) for g in grads_ref.values())
+    bad = []
     for n, p in net._model.named_parameters():
         g = p.grad.cpu()
         gr = grads_ref[n]
-        scale = float(gr.abs().max())
-        if scale < 1e-10:   # conv biases in front of BatchNorm: exact zero in exact arithmetic
-            assert float(g.abs().max()) < 1e-6
-            continue
-        worst = max(worst, float((g - gr).abs().max()) / scale)
-    assert worst < 2e-3, worst
+        err = float((g - gr).abs().max())
+        # PReLU alpha / bias gradients are single global sums with heavy cancellation
+        rtol = 2e-2 if (n.endswith(".A.weight") or n.endswith(".bias")) else 2e-3
+        lim = rtol * float(gr.abs().max()) + 2e-6 * gmax
+        if err > lim:
+            bad.append((n, err, float(gr.abs().max())))
+    assert not bad, bad[:8]
     # post-Adam parameters and BN running statistics
     sd_ref = ref.state_dict()
     for kk, v in net._model.state_dict().items():
@@ -89,7 +92,7 @@ def test_train_step_parity_f32(cfg):
     # the gradient is well above rounding noise
     for n, p in net._model.named_parameters():
         gr = grads_ref[n]
-        mask = gr.abs() > 1e-3 * gr.abs().max().clamp(min=1e-12)
+        mask = gr.abs() > 1e-3 * gmax   # Adam's first step is lr*sign(g): skip rounding-noise gradients
         if mask.any():
             d_ref = (dict(ref.named_parameters())[n].detach() - p.detach().cpu())[mask].abs().max()
             assert float(d_ref) < 5e-6, (n, float(d_ref))
