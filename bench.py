@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native segmantic hot path.
+
+Workload (BASELINE.json configs[1]): one training step of the reference's 3D residual UNet
+(1 input channel, 16 labels, channels 16-32-64-128-256) on a batch of 8 synthetic 128^3 patches
+(the reference's batch: 2 volumes x num_samples 4, monai_unet.py:82,279-285), bf16 storage /
+f32 accumulation: forward -> Dice loss -> backward -> Adam, exactly the order of
+``training_step`` (monai_unet.py:339-348).  Metric: training voxels per second, whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|infer]
+
+N > 1 is launched by torchrun (one rank per GPU, RCCL); every rank trains on its own batch (weak
+scaling) with the gradient arena all-reduced in buckets overlapped with backward.
+
+Output: ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     dominant kernel (full-resolution 16->16 conv forward, 49 % of the FLOPs) timed
+               live with HIP events on its launch stream; MFMA-bound nominally, peak 2.5 PFLOP/s
+  cpu_baseline the CPU oracle (torch-CPU restatement of the reference path) timed on the host
+               cores on a bounded sample (N=1, rank 0 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_VOXEL_FWD_K16 = 28204.0       # 59.148 GFLOP / 128^3
+FLOP_PER_VOXEL_TRAIN_K16 = 84396.0     # fwd + dgrad + wgrad
+TOP_CONV_FLOP_PER_VOXEL = 2.0 * 27 * 16 * 16   # 16->16 k3 conv at full resolution
+MFMA_PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
+MFMA_PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="train", choices=["train", "infer"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--classes", type=int, default=16)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--volume", type=int, default=512, help="infer: cubic volume extent")
+    ap.add_argument("--overlap", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=128)
+    return ap.parse_args()
+
+
+def synthetic(batch, size, classes, seed, device):
+    """randn images, blob-like integer labels stored as float."""
+    g = torch.Generator(device="cpu").manual_seed(1234 + seed)
+    img = torch.randn((batch, 1, size, size, size), generator=g)
+    ax = torch.arange(size, dtype=torch.float32)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    lab = torch.empty((batch, 1, size, size, size))
+    for b in range(batch):
+        c = [size * (0.35 + 0.3 * ((b * 7 + i * 3 + seed) % 5) / 4.0) for i in range(3)]
+        r = torch.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2)
+        lab[b, 0] = torch.clamp(torch.floor(classes * (1.0 - r / (0.75 * size))), 0, classes - 1)
+    return img.to(device), lab.to(device)
+
+
+def cpu_baseline_train(size, classes, steps=3):
+    """The CPU oracle (port of the reference path) on this host's cores, bounded sample."""
+    from oracle.unet_ref import RefUNet, deterministic_fill_, ref_train_step, synthetic_batch
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    net = deterministic_fill_(RefUNet(3, 1, classes), 0).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    img, lab = synthetic_batch(1, size, classes, seed=0)
+    ref_train_step(net, opt, img, lab)  # warm-up
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        ref_train_step(net, opt, img, lab)
+        ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    return {"value": size ** 3 / best, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed training steps (best) of the torch-CPU oracle, batch 1 x "
+                      f"{size}^3, {classes} labels, fp32, after 1 warm-up"}
+
+
+def cpu_baseline_infer(classes, vol=256, roi=128, overlap=0.5):
+    from oracle.sliding_ref import ref_sliding_window_inference
+    from oracle.unet_ref import RefUNet, deterministic_fill_
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    net = deterministic_fill_(RefUNet(3, 1, classes), 0).eval()
+    img = torch.randn((1, 1, vol, vol, vol))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref_sliding_window_inference(img, (roi,) * 3, 4, net, overlap)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt * (vol / 512.0) ** 3, "unit": "volumes/s (512^3-equivalent)",
+            "cores": threads, "kind": "port",
+            "sample": f"one {vol}^3 volume, roi {roi}^3, overlap {overlap}, scaled by voxel count to 512^3"}
+
+
+def main():
+    args = parse()
+    from segmantic_amd.seg.distributed import init_distributed
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+
+    from segmantic_amd.seg.monai_unet import Net
+
+    K = args.classes
+    net = Net(num_classes=K, num_channels=1, spatial_size=[args.size] * 3)
+    net.mixed_precision = args.precision == "bf16"
+    net.to(device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    top_key = "2.1.conv.unit0.conv:fwd"
+    if args.workload == "train":
+        net.train()
+        if world > 1:
+            net.enable_grad_sync()
+        img, lab = synthetic(args.batch, args.size, K, rank, device)
+        batch = {"image": img, "label": lab}
+        for _ in range(args.warmup):
+            net.training_step(batch)
+        eng = net._engine
+        eng.timed = {top_key}
+        eng.timings.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net.training_step(batch)
+        barrier()
+        dt = time.perf_counter() - t0
+        units = args.batch * args.size ** 3 * args.steps
+        metric, unit = "3D UNet train voxels/s on 128^3 bf16", "voxels/s"
+        workload = (f"training_step (fwd + Dice + bwd + Adam) of the 5-level residual UNet, "
+                    f"batch {args.batch} x 1ch x {args.size}^3, {K} labels, {args.precision}")
+        kern_units = args.batch * args.size ** 3
+        cfg = {"workload": workload, "global_batch": args.batch * world, "patch": args.size,
+               "labels": K, "parallelism": f"dp{world}"}
+    else:
+        net.eval()
+        from segmantic_amd.seg.inferers import sliding_window_inference
+        V = args.volume
+        g = torch.Generator().manual_seed(99 + rank)
+        vol = torch.randn((1, 1, V, V, V), generator=g).to(device)
+        wdt = torch.bfloat16 if net.mixed_precision else torch.float32
+
+        def run():
+            with torch.no_grad():
+                return sliding_window_inference(vol, (args.size,) * 3, 4, net, overlap=args.overlap,
+                                                return_labels=True, window_dtype=torch.float32)
+        for _ in range(args.warmup):
+            run()
+        eng = net._engine
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        dt = time.perf_counter() - t0
+        units = args.steps
+        metric, unit = "sliding-window infer vols/s", "volumes/s"
+        cfg = {"workload": f"sliding_window_inference of one {V}^3 volume, roi {args.size}^3, overlap "
+                           f"{args.overlap}, sw_batch 4, {K} labels, {args.precision}, gather+forward+blend+argmax on device",
+               "parallelism": f"replicas{world}"}
+        kern_units = None
+
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = units * world / dt
+
+    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": cfg}
+
+    if rank == 0:
+        if args.workload == "train":
+            ms = eng.timing_ms(top_key)
+            if ms:
+                avg = statistics.mean(ms)
+                flops = kern_units * TOP_CONV_FLOP_PER_VOXEL
+                ach = flops / (avg * 1e-3) / 1e12
+                peak = MFMA_PEAK_BF16_TFLOPS if args.precision == "bf16" else MFMA_PEAK_F32_TFLOPS
+                es = 2 if args.precision == "bf16" else 4
+                out["roofline"] = {
+                    "kernel": "conv_fwd_mfma_kernel (full-resolution 16->16 k3 conv + residual epilogue)",
+                    "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ach / peak, "traffic": None,
+                    "avg_launch_ms": avg, "launches": len(ms),
+                    "algorithmic_flops_per_launch": flops,
+                    "hbm_view": {"algorithmic_bytes_per_launch": kern_units * 16 * es * 3,
+                                 "achieved_GBps": kern_units * 16 * es * 3 / (avg * 1e-3) / 1e9,
+                                 "peak_GBps": 8000.0},
+                }
+            step_flops = args.batch * args.size ** 3 * FLOP_PER_VOXEL_TRAIN_K16 if K == 16 else None
+            if step_flops:
+                out["config"]["step_conv_TFLOPs"] = step_flops / 1e12
+                out["config"]["whole_step_TFLOP_per_s_per_gpu"] = step_flops / (dt / args.steps) / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                if args.workload == "train":
+                    out["cpu_baseline"] = cpu_baseline_train(args.cpu_size, K)
+                else:
+                    out["cpu_baseline"] = cpu_baseline_infer(K)
+            except Exception as e:  # the baseline is informative; never lose the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

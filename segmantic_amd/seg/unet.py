@@ -251,6 +251,7 @@ class UNetEngine:
         self._bufs: Dict[str, torch.Tensor] = {}
         self._scratch: Dict[str, torch.Tensor] = {}
         self._saved: Dict[str, torch.Tensor] = {}
+        self.timings: Dict[str, list] = {}
         self._build_arena()
         self._build_plan()
 
@@ -384,10 +385,11 @@ class UNetEngine:
                     else ops.conv3d_stats_rows(x, y, conv.k, conv.stride))
             stats = self._fstat(rows, conv.cout)
         if conv.transposed:
-            ops.convT3d_fwd(x, y, conv.fwd_pack(), conv.w, conv.b, stats=stats)
+            self._timed(conv.prefix + ":fwd", ops.convT3d_fwd, x, y, conv.fwd_pack(), conv.w,
+                        conv.b, stats=stats)
         else:
-            ops.conv3d_fwd(x, y, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
-                           stats=stats)
+            self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, x, y, conv.fwd_pack(), conv.w, 0,
+                        conv.b, conv.k, conv.stride, stats=stats)
         if bn is not None:
             count = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
             ops.bn_finalize(stats, rows, conv.cout, count, bn.gamma, bn.beta, bn.rm, bn.rv,
@@ -405,7 +407,8 @@ class UNetEngine:
         else:
             nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
             ws = self._scratch_buf("wgrad", nbytes)
-            ops.conv3d_wgrad(x, dy, conv.gw, conv.gb, conv.k, conv.stride, ws)
+            self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw, conv.gb, conv.k,
+                        conv.stride, ws)
 
     def _dgrad(self, conv: _Conv, dy, dx, residual=None):
         """dx = dgrad(conv, dy) (+ residual)."""
@@ -445,8 +448,8 @@ class UNetEngine:
             last = i == nun - 1
             if bn is None:
                 # conv-only last unit (top of the net): out = conv(cur) + residual
-                ops.conv3d_fwd(cur, out, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
-                               residual=resid)
+                self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, cur, out, conv.fwd_pack(), conv.w,
+                            0, conv.b, conv.k, conv.stride, residual=resid)
                 saved[f"in{i}"] = cur
                 break
             r = self._buf(f"{pre}.r{i}", (n, d, h, w, conv.cout))
@@ -621,6 +624,24 @@ class UNetEngine:
         if not self._saved:
             raise RuntimeError("backward() needs a preceding training-mode forward()")
         self._level_bwd(self.levels, dlogits)
+
+    # ------------------------------------------------------------------ live kernel timing
+    # bench.py sets `timed = {"<conv prefix>:<fwd|wgrad|dgrad>"}`; the matching C-ABI call is
+    # bracketed by HIP events on the launch stream (torch's current stream).
+    timed: Optional[set] = None
+
+    def _timed(self, key: str, fn, *a, **k):
+        if not self.timed or key not in self.timed:
+            return fn(*a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn(*a, **k)
+        e.record()
+        self.timings.setdefault(key, []).append((s, e))
+        return out
+
+    def timing_ms(self, key: str) -> List[float]:
+        return [s.elapsed_time(e) for s, e in self.timings.get(key, [])]
 
     grad_hook = None  # callable(lo_offset): gradients at arena offsets >= lo are final
 
