@@ -71,10 +71,23 @@ def synthetic(batch, size, classes, seed, device):
     return img.to(device), lab.to(device)
 
 
+def host_cores() -> int:
+    """CPU share of this process: affinity mask capped by the cgroup quota (the GPU box exposes
+    256 logical CPUs but grants a 16-CPU quota; oversubscribing torch threads is ~40x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline_train(size, classes, steps=3):
     """The CPU oracle (port of the reference path) on this host's cores, bounded sample."""
     from oracle.unet_ref import RefUNet, deterministic_fill_, ref_train_step, synthetic_batch
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     net = deterministic_fill_(RefUNet(3, 1, classes), 0).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
@@ -94,7 +107,7 @@ def cpu_baseline_train(size, classes, steps=3):
 def cpu_baseline_infer(classes, vol=256, roi=128, overlap=0.5):
     from oracle.sliding_ref import ref_sliding_window_inference
     from oracle.unet_ref import RefUNet, deterministic_fill_
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     net = deterministic_fill_(RefUNet(3, 1, classes), 0).eval()
     img = torch.randn((1, 1, vol, vol, vol))

@@ -12,6 +12,10 @@ int convt_mfma_f32(const ConvTParams& p, hipStream_t st);
 int convt_mfma_bf16(const ConvTParams& p, hipStream_t st);
 int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
 int bn_stats_rows_for(const segmi_act* x);
+int stats_reserve_rows();
+bool conv_small_ok(int cin, int cout, int ksize);
+int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
+                   const float* bias, int stride, hipStream_t st);
 
 struct DirectParams {
   const void* in;
@@ -126,8 +130,8 @@ int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out
                             int stride) {
   (void)dtype; (void)ksize;
   if (!in || !out) return 0;
-  if (mfma_ok(in->c, out->c)) return conv_mfma_rows(out, stride);
-  return bn_stats_rows_for(out);
+  if (mfma_ok(in->c, out->c)) return conv_mfma_rows(out, stride) + stats_reserve_rows();
+  return bn_stats_rows_for(out) + stats_reserve_rows();
 }
 
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
@@ -172,6 +176,13 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
   }
   SEGMI_CHECK_ARG(w_src, "conv3d: direct path (channels not multiples of 16) needs w_src");
   SEGMI_CHECK_ARG(w_kind == 0 || w_kind == 1, "conv3d: bad w_kind %d", w_kind);
+  if (conv_small_ok(in->c, out->c, ksize) && w_kind == 0 && !prelu_alpha && !residual &&
+      out->ld % 4 == 0 && ((uintptr_t)out->data % (4 * es)) == 0) {
+    const int rc = conv_small_fwd(dtype, in, out, w_src, bias, stride, st);
+    if (rc) return rc;
+    if (stats_partials) return bn_stats_launch(dtype, out, stats_partials, st);
+    return SEGMI_OK;
+  }
   DirectParams p{};
   p.in = in->data; p.out = out->data; p.w = w_src; p.bias = bias; p.alpha = prelu_alpha;
   p.res = residual ? residual->data : nullptr;
@@ -194,8 +205,8 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
 int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out) {
   (void)dtype;
   if (!in || !out) return 0;
-  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(in);
-  return bn_stats_rows_for(out);
+  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(in) + stats_reserve_rows();
+  return bn_stats_rows_for(out) + stats_reserve_rows();
 }
 
 int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,

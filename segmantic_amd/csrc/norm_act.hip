@@ -7,8 +7,13 @@
 namespace segmi {
 
 constexpr int kStatVox = 4096;  // voxels per workgroup in the reduction kernels
+constexpr int kCollapseBlocks = 64;
+// rows reserved behind every caller-visible partial buffer for the f64 stage-1 result:
+// 64 blocks x width doubles = 128 rows of `width` floats (+1 for 8-byte alignment)
+constexpr int kReserveRows = 2 * kCollapseBlocks + 1;
 
 int bn_stats_rows_for(const segmi_act* x) { return (int)cdiv64(act_voxels(x), kStatVox); }
+int stats_reserve_rows() { return kReserveRows; }
 
 template <typename T, int VEC>
 __device__ __forceinline__ void loadv(const T* p, float (&v)[VEC]) {
@@ -116,9 +121,46 @@ int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t 
   return SEGMI_OK;
 }
 
-// partials [rows][2][c] -> per-channel statistics (f64 accumulation, fixed order)
+// Stage 1 of every partial-row reduction: [rows][width] f32 -> [kCollapseBlocks][width] f64,
+// fixed order (block b owns rows b*rl + lane, stepping by nblk*rl).  The f64 result lives in a
+// scratch tail that the *_rows() entry points reserve behind the caller's partial buffer.
+__global__ __launch_bounds__(256) void collapse_rows_kernel(const float* __restrict__ in, int rows,
+                                                            int width, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int wl = width < 256 ? width : 256;
+  const int rl = 256 / wl;
+  const int tid = threadIdx.x;
+  for (int w0 = 0; w0 < width; w0 += wl) {
+    const int e = w0 + tid % wl, lane = tid / wl;
+    double s = 0.0;
+    if (lane < rl && e < width)
+      for (int r = blockIdx.x * rl + lane; r < rows; r += gridDim.x * rl)
+        s += (double)in[(int64_t)r * width + e];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < wl && w0 + tid < width) {
+      double t = 0.0;
+      for (int l = 0; l < rl; ++l) t += red[l * wl + tid];
+      out[(int64_t)blockIdx.x * width + w0 + tid] = t;
+    }
+    __syncthreads();
+  }
+}
+
+static inline double* collapse_scratch(const float* partials, int real_rows, int width) {
+  uintptr_t p = (uintptr_t)(partials + (int64_t)real_rows * width);
+  return (double*)((p + 7) & ~(uintptr_t)7);
+}
+static int collapse_launch(const float* partials, int real_rows, int width, hipStream_t st) {
+  hipLaunchKernelGGL(collapse_rows_kernel, kCollapseBlocks, 256, 0, st, partials, real_rows, width,
+                     collapse_scratch(partials, real_rows, width));
+  SEGMI_LAUNCH_CHECK("collapse_rows");
+  return SEGMI_OK;
+}
+
+// collapsed [rows][2][c] f64 -> per-channel statistics (fixed order)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partials, int rows, int c, double count, const float* gamma,
+    const double* __restrict__ partials, int rows, int c, double count, const float* gamma,
     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
     float* mean, float* invstd, float* scale, float* shift) {
   __shared__ double red[2][256];
@@ -130,8 +172,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     double s = 0.0, q = 0.0;
     if (part < parts && ch < c) {
       for (int r = part; r < rows; r += parts) {
-        s += (double)partials[((int64_t)r * 2 + 0) * c + ch];
-        q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
+        s += partials[((int64_t)r * 2 + 0) * c + ch];
+        q += partials[((int64_t)r * 2 + 1) * c + ch];
       }
     }
     red[0][tid] = s; red[1][tid] = q;
@@ -270,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
 
 // partials -> dgamma, dbeta, dalpha(sum over channels), coef[2][c] = {mean dz, mean dz*xhat}
 __global__ __launch_bounds__(256) void bn_act_bwd_finalize_kernel(
-    const float* __restrict__ partials, int rows, int c, double count, float* dgamma,
+    const double* __restrict__ partials, int rows, int c, double count, float* dgamma,
     float* dbeta, float* dalpha, float* coef) {
   __shared__ double red[3][256];
   __shared__ double asum[256];
@@ -283,9 +325,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_finalize_kernel(
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     if (part < parts && ch < c) {
       for (int r = part; r < rows; r += parts) {
-        s0 += (double)partials[((int64_t)r * 3 + 0) * c + ch];
-        s1 += (double)partials[((int64_t)r * 3 + 1) * c + ch];
-        s2 += (double)partials[((int64_t)r * 3 + 2) * c + ch];
+        s0 += partials[((int64_t)r * 3 + 0) * c + ch];
+        s1 += partials[((int64_t)r * 3 + 1) * c + ch];
+        s2 += partials[((int64_t)r * 3 + 2) * c + ch];
       }
     }
     red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
@@ -415,7 +457,7 @@ using namespace segmi;
 
 extern "C" {
 
-int segmi_bn_stats_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) : 0; }
+int segmi_bn_stats_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) + kReserveRows : 0; }
 
 int segmi_bn_stats(int dtype, const segmi_act* x, float* stats_partials, void* stream) {
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_stats: bad dtype");
@@ -427,9 +469,15 @@ int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count
                       const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, float* mean,
                       float* invstd, float* scale, float* shift, void* stream) {
-  SEGMI_CHECK_ARG(stats_partials && rows > 0 && c > 0 && count > 0 && mean && invstd && scale &&
-                      shift, "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, 1, 256, 0, (hipStream_t)stream, stats_partials, rows, c,
+  SEGMI_CHECK_ARG(stats_partials && rows > kReserveRows && c > 0 && count > 0 && mean && invstd &&
+                      scale && shift,
+                  "bn_finalize: bad arguments (rows must come from a *_stats_rows() call)");
+  const int real = rows - kReserveRows;
+  const int rc = collapse_launch(stats_partials, real, 2 * c, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, 1, 256, 0, (hipStream_t)stream,
+                     (const double*)collapse_scratch(stats_partials, real, 2 * c),
+                     kCollapseBlocks, c,
                      count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
                      scale, shift);
   SEGMI_LAUNCH_CHECK("bn_finalize");
@@ -470,7 +518,7 @@ int segmi_add(int dtype, const segmi_act* a, const segmi_act* b, const segmi_act
   return segmi_bn_act_fwd(dtype, a, out, nullptr, nullptr, nullptr, b, stream);
 }
 
-int segmi_bn_act_bwd_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) : 0; }
+int segmi_bn_act_bwd_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) + kReserveRows : 0; }
 
 int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
                             const float* mean, const float* invstd, const float* gamma,
@@ -495,10 +543,15 @@ int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double
                               const float* gamma, const float* invstd, float* dgamma,
                               float* dbeta, float* dalpha, float* coef, void* stream) {
   (void)gamma; (void)invstd;
-  SEGMI_CHECK_ARG(red_partials && rows > 0 && c > 0 && count > 0 && coef,
-                  "bn_act_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, 1, 256, 0, (hipStream_t)stream, red_partials,
-                     rows, c, count, dgamma, dbeta, dalpha, coef);
+  SEGMI_CHECK_ARG(red_partials && rows > kReserveRows && c > 0 && count > 0 && coef,
+                  "bn_act_bwd_finalize: bad arguments (rows must come from bn_act_bwd_rows())");
+  const int real = rows - kReserveRows;
+  const int rc = collapse_launch(red_partials, real, 3 * c, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, 1, 256, 0, (hipStream_t)stream,
+                     (const double*)collapse_scratch(red_partials, real, 3 * c),
+                     kCollapseBlocks, c, count, dgamma, dbeta,
+                     dalpha, coef);
   SEGMI_LAUNCH_CHECK("bn_act_bwd_finalize");
   return SEGMI_OK;
 }

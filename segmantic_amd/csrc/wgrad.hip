@@ -3,10 +3,14 @@
 
 namespace segmi {
 
-int wgrad_mfma_f32(const WgradParams& p, int stride, int ct, int gx, hipStream_t st);
-int wgrad_mfma_bf16(const WgradParams& p, int stride, int ct, int gx, hipStream_t st);
+int wgrad_mfma_f32(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
+int wgrad_mfma_bf16(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
 int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
 int bn_stats_rows_for(const segmi_act* x);
+bool conv_small_ok(int cin, int cout, int ksize);
+int conv_small_wgrad_slabs(const segmi_act* dy);
+int conv_small_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* partials,
+                     int stride, hipStream_t st);
 
 struct WgDirectParams {
   const void* x;
@@ -17,7 +21,7 @@ struct WgDirectParams {
   int chunk;
 };
 
-// direct fallback: block b reduces voxel chunks b, b+grid, ...; thread loops outputs
+// direct fallback (odd channel counts): block b reduces voxel chunks b, b+grid, ...
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgDirectParams p) {
   const int nt = p.ks * p.ks * p.ks, pad = (p.ks - 1) / 2;
@@ -55,30 +59,66 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgDirectParams p) {
 __global__ void slab_reduce_kernel(const float* __restrict__ partials, int nslab, int64_t n,
                                    float* __restrict__ out) {
   for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    double acc = 0.0;
-    for (int b = 0; b < nslab; ++b) acc += (double)partials[(int64_t)b * n + e];
-    out[e] = (float)acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+      a0 += (double)partials[(int64_t)b * n + e];
+      a1 += (double)partials[(int64_t)(b + 1) * n + e];
+      a2 += (double)partials[(int64_t)(b + 2) * n + e];
+      a3 += (double)partials[(int64_t)(b + 3) * n + e];
+    }
+    for (; b < nslab; ++b) a0 += (double)partials[(int64_t)b * n + e];
+    out[e] = (float)((a0 + a1) + (a2 + a3));
   }
 }
 
-// stats partials [rows][2][c] -> db[c] = sum of the "sum" rows
-__global__ void bias_reduce_kernel(const float* __restrict__ partials, int rows, int c,
-                                   float* __restrict__ db) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double acc = 0.0;
-  for (int r = 0; r < rows; ++r) acc += (double)partials[((int64_t)r * 2) * c + ch];
-  db[ch] = (float)acc;
+// stats partials [rows][2][c] -> db[c] = sum of the "sum" rows (f64, fixed order)
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ partials,
+                                                          int rows, int c, float* __restrict__ db) {
+  __shared__ double red[256];
+  const int cp = c < 256 ? c : 256;
+  const int parts = 256 / cp;
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < c; c0 += cp) {
+    const int ch = c0 + tid % cp, part = tid / cp;
+    double s = 0.0;
+    if (part < parts && ch < c)
+      for (int r = part; r < rows; r += parts) s += (double)partials[((int64_t)r * 2) * c + ch];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < cp && c0 + tid < c) {
+      double t = 0.0;
+      for (int pi = 0; pi < parts; ++pi) t += red[pi * cp + tid];
+      db[c0 + tid] = (float)t;
+    }
+    __syncthreads();
+  }
 }
 
-static inline bool wg_mfma_ok(const segmi_act* x, const segmi_act* dy, int ksize) {
-  return ksize == 3 && x->c % 16 == 0 && dy->c % 16 == 0;
+static inline bool aligned_rows(const segmi_act* a, int dtype) {
+  const int es = dtype_size(dtype);
+  return a->ld % (16 / es) == 0 && ((uintptr_t)a->data % 16) == 0;
+}
+static inline bool wg_mfma_ok(int dtype, const segmi_act* x, const segmi_act* dy, int ksize) {
+  return x->c % 16 == 0 && dy->c % 16 == 0 && aligned_rows(x, dtype) && aligned_rows(dy, dtype) &&
+         (ksize == 3 || ksize == 1);
+}
+static inline bool wg_small_ok(int dtype, const segmi_act* x, const segmi_act* dy, int ksize) {
+  const int es = dtype_size(dtype);
+  return conv_small_ok(x->c, dy->c, ksize) && dy->ld % 4 == 0 &&
+         ((uintptr_t)dy->data % (4 * es)) == 0;
 }
 static inline int wg_direct_blocks(const segmi_act* dy) {
   const int64_t b = cdiv64(act_voxels(dy), 512);
   return (int)(b > 1024 ? 1024 : b);
 }
 static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+static inline int wg_slabs(int dtype, const segmi_act* x, const segmi_act* dy, int ksize,
+                           int stride) {
+  if (wg_mfma_ok(dtype, x, dy, ksize)) return wgrad_gx(dtype, x, dy, stride);
+  if (wg_small_ok(dtype, x, dy, ksize)) return conv_small_wgrad_slabs(dy);
+  return wg_direct_blocks(dy);
+}
 
 }  // namespace segmi
 
@@ -90,7 +130,7 @@ int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_
                                      int ksize, int stride) {
   if (!x || !dy) return 0;
   const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
-  const int slabs = wg_mfma_ok(x, dy, ksize) ? wgrad_gx(dtype, x, dy, stride) : wg_direct_blocks(dy);
+  const int slabs = wg_slabs(dtype, x, dy, ksize, stride);
   const int64_t bias = (int64_t)bn_stats_rows_for(dy) * 2 * dy->c * 4;
   return align256(slabs * nout * 4) + align256(bias);
 }
@@ -100,7 +140,7 @@ int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, 
   hipStream_t st = (hipStream_t)stream;
   int rc = bn_stats_launch(dtype, dy, (float*)workspace, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(bias_reduce_kernel, cdiv(dy->c, 256), 256, 0, st, (const float*)workspace,
+  hipLaunchKernelGGL(bias_reduce_kernel, 1, 256, 0, st, (const float*)workspace,
                      bn_stats_rows_for(dy), dy->c, db);
   SEGMI_LAUNCH_CHECK("bias_grad");
   return SEGMI_OK;
@@ -111,6 +151,7 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "wgrad: bad dtype");
   SEGMI_CHECK_ARG(act_ok(x) && act_ok(dy) && dw && workspace, "wgrad: bad arguments");
   SEGMI_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "wgrad: k/s");
+  SEGMI_CHECK_ARG(!(ksize == 1 && stride != 1), "wgrad: k1 is stride 1 only");
   const int pad = (ksize - 1) / 2;
   SEGMI_CHECK_ARG(x->n == dy->n && dy->d == (x->d + 2 * pad - ksize) / stride + 1 &&
                       dy->h == (x->h + 2 * pad - ksize) / stride + 1 &&
@@ -119,20 +160,18 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
   hipStream_t st = (hipStream_t)stream;
   const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
   float* partials = (float*)workspace;
-  int slabs;
-  const int es = dtype_size(dtype);
-  if (wg_mfma_ok(x, dy, ksize)) {
-    SEGMI_CHECK_ARG(x->ld % (16 / es) == 0 && dy->ld % (16 / es) == 0 &&
-                        ((uintptr_t)x->data % 16) == 0 && ((uintptr_t)dy->data % 16) == 0,
-                    "wgrad: MFMA path needs 16-byte aligned rows");
+  const int slabs = wg_slabs(dtype, x, dy, ksize, stride);
+  if (wg_mfma_ok(dtype, x, dy, ksize)) {
     WgradParams p{};
     p.x = x->data; p.dy = dy->data; p.partials = partials;
     p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
     p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
     const int ct = wgrad_ct(dtype, x->c, dy->c);
-    slabs = wgrad_gx(dtype, x, dy, stride);
-    const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, stride, ct, slabs, st)
-                                      : wgrad_mfma_bf16(p, stride, ct, slabs, st);
+    const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, slabs, st)
+                                      : wgrad_mfma_bf16(p, ksize, stride, ct, slabs, st);
+    if (rc) return rc;
+  } else if (wg_small_ok(dtype, x, dy, ksize)) {
+    const int rc = conv_small_wgrad(dtype, x, dy, partials, stride, st);
     if (rc) return rc;
   } else {
     WgDirectParams p{};
@@ -140,7 +179,6 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
     p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
     p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld; p.ks = ksize; p.stride = stride;
     p.nvox = act_voxels(dy); p.chunk = 512;
-    slabs = wg_direct_blocks(dy);
     if (dtype == SEGMI_F32) hipLaunchKernelGGL(wgrad_direct_kernel<float>, slabs, 256, 0, st, p);
     else hipLaunchKernelGGL(wgrad_direct_kernel<bf16_t>, slabs, 256, 0, st, p);
     SEGMI_LAUNCH_CHECK("conv3d_wgrad(direct)");

@@ -34,9 +34,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) float lds_f32;
 
-template <typename T, int S, int CT, int TD, int TH, int TW>
+template <typename T, int KS_, int S, int CT, int TD, int TH, int TW>
 struct WgradGeom {
-  static constexpr int KS = 3, PAD = 1, NTAPS = 27;
+  static constexpr int KS = KS_, PAD = (KS_ - 1) / 2, NTAPS = KS_ * KS_ * KS_;
+  static constexpr int NTW = (NTAPS + 3) / 4;  // taps per wave
   static constexpr int NV = TD * TH * TW;
   static constexpr int NL = NV / 16;  // 16-voxel lines
   static constexpr int HD = (TD - 1) * S + KS, HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
@@ -59,9 +60,9 @@ __device__ __forceinline__ constexpr int wg_line_row(int line) {
   return (z * S * HH + y * S) * HW;
 }
 
-template <typename T, int S, int CT, int TD, int TH, int TW>
+template <typename T, int KS, int S, int CT, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
-  using G = WgradGeom<T, S, CT, TD, TH, TW>;
+  using G = WgradGeom<T, KS, S, CT, TD, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ysm = smem;
   char* xsm = smem + G::YBYTES;
@@ -72,21 +73,21 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   const int cochunk = blockIdx.y / p.ci_chunks, cichunk = blockIdx.y % p.ci_chunks;
   const int co0 = cochunk * 16 * CT, ci0 = cichunk * 16 * CT;
 
-  f32x4 acc[7][CT][CT];
+  f32x4 acc[G::NTW][CT][CT];
 #pragma unroll
-  for (int a = 0; a < 7; ++a)
+  for (int a = 0; a < G::NTW; ++a)
 #pragma unroll
     for (int b = 0; b < CT; ++b)
 #pragma unroll
       for (int c = 0; c < CT; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // wave-uniform tap offsets (bytes into the X tile)
-  int tapoff[7];
+  int tapoff[G::NTW];
 #pragma unroll
-  for (int ti = 0; ti < 7; ++ti) {
+  for (int ti = 0; ti < G::NTW; ++ti) {
     int tap = wave + 4 * ti;
-    if (tap > 26) tap = 26;
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    if (tap > G::NTAPS - 1) tap = G::NTAPS - 1;
+    const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
     tapoff[ti] = ((kd * G::HH + kh) * G::HW + kw) * G::ROWB;
   }
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     const int tzi = t % p.tz;
     const int n = t / p.tz;
     const int oz0 = tzi * TD, oy0 = tyi * TH, ox0 = txi * TW;
-    const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int iz0 = oz0 * S - G::PAD, iy0 = oy0 * S - G::PAD, ix0 = ox0 * S - G::PAD;
     __syncthreads();
     // stage dY tile [NV][16*CT]
     for (int i = tid; i < G::NV * G::CPR; i += 256) {
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
         }
       }
 #pragma unroll
-      for (int ti = 0; ti < 7; ++ti) {
+      for (int ti = 0; ti < G::NTW; ++ti) {
+        if (KS == 1 && wave != 0) break;  // k1: a single tap, owned by wave 0
         frag_t bf[CT];
         if constexpr (sizeof(T) == 2) {
           const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg) * G::ROWB;
@@ -197,11 +199,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   }
 
   // partial slab [block][Cout][Cin][27]
-  float* slab = p.partials + (int64_t)blockIdx.x * p.Cout * p.Cin * 27;
+  float* slab = p.partials + (int64_t)blockIdx.x * p.Cout * p.Cin * G::NTAPS;
 #pragma unroll
-  for (int ti = 0; ti < 7; ++ti) {
+  for (int ti = 0; ti < G::NTW; ++ti) {
     const int tap = wave + 4 * ti;
-    if (tap < 27) {
+    if (tap < G::NTAPS) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -209,15 +211,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int co = co0 + ct * 16 + 4 * g + e, ci = ci0 + it * 16 + i16;
-            slab[((int64_t)co * p.Cin + ci) * 27 + tap] = acc[ti][ct][it][e];
+            slab[((int64_t)co * p.Cin + ci) * G::NTAPS + tap] = acc[ti][ct][it][e];
           }
     }
   }
 }
 
-template <typename T, int S, int CT, int TD, int TH, int TW>
+template <typename T, int KS, int S, int CT, int TD, int TH, int TW>
 static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
-  using G = WgradGeom<T, S, CT, TD, TH, TW>;
+  using G = WgradGeom<T, KS, S, CT, TD, TH, TW>;
   p.tz = cdiv(p.Dy, TD);
   p.ty = cdiv(p.Hy, TH);
   p.tx = cdiv(p.Wy, TW);
@@ -225,7 +227,7 @@ static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
   p.ci_chunks = p.Cin / (16 * CT);
   const int co_chunks = p.Cout / (16 * CT);
   dim3 grid((unsigned)gx_hint, (unsigned)(co_chunks * p.ci_chunks));
-  auto kern = wgrad_mfma_kernel<T, S, CT, TD, TH, TW>;
+  auto kern = wgrad_mfma_kernel<T, KS, S, CT, TD, TH, TW>;
   static bool attr_done = false;
   if (!attr_done && G::LDS_BYTES > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -258,20 +260,29 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
 }
 
 template <typename T>
-static int launch_wgrad_mfma_t(const WgradParams& p, int stride, int ct, int gx, hipStream_t st) {
+static int launch_wgrad_mfma_t(const WgradParams& p, int ksize, int stride, int ct, int gx,
+                               hipStream_t st) {
   const bool wide = p.Wy > 8;
+  if (ksize == 1) {
+    if constexpr (sizeof(T) == 2) {
+      if (ct == 2) return wide ? launch_wgrad_cfg<T, 1, 1, 2, 2, 8, 16>(p, gx, st)
+                               : launch_wgrad_cfg<T, 1, 1, 2, 4, 8, 8>(p, gx, st);
+    }
+    return wide ? launch_wgrad_cfg<T, 1, 1, 1, 2, 8, 16>(p, gx, st)
+                : launch_wgrad_cfg<T, 1, 1, 1, 4, 8, 8>(p, gx, st);
+  }
   if constexpr (sizeof(T) == 2) {
     if (ct == 2) {
-      if (stride == 1) return wide ? launch_wgrad_cfg<T, 1, 2, 2, 8, 16>(p, gx, st)
-                                   : launch_wgrad_cfg<T, 1, 2, 4, 8, 8>(p, gx, st);
-      return wide ? launch_wgrad_cfg<T, 2, 2, 2, 4, 16>(p, gx, st)
-                  : launch_wgrad_cfg<T, 2, 2, 2, 8, 8>(p, gx, st);
+      if (stride == 1) return wide ? launch_wgrad_cfg<T, 3, 1, 2, 2, 8, 16>(p, gx, st)
+                                   : launch_wgrad_cfg<T, 3, 1, 2, 4, 8, 8>(p, gx, st);
+      return wide ? launch_wgrad_cfg<T, 3, 2, 2, 2, 4, 16>(p, gx, st)
+                  : launch_wgrad_cfg<T, 3, 2, 2, 2, 8, 8>(p, gx, st);
     }
   }
-  if (stride == 1) return wide ? launch_wgrad_cfg<T, 1, 1, 2, 8, 16>(p, gx, st)
-                               : launch_wgrad_cfg<T, 1, 1, 4, 8, 8>(p, gx, st);
-  return wide ? launch_wgrad_cfg<T, 2, 1, 2, 4, 16>(p, gx, st)
-              : launch_wgrad_cfg<T, 2, 1, 2, 8, 8>(p, gx, st);
+  if (stride == 1) return wide ? launch_wgrad_cfg<T, 3, 1, 1, 2, 8, 16>(p, gx, st)
+                               : launch_wgrad_cfg<T, 3, 1, 1, 4, 8, 8>(p, gx, st);
+  return wide ? launch_wgrad_cfg<T, 3, 2, 1, 2, 4, 16>(p, gx, st)
+              : launch_wgrad_cfg<T, 3, 2, 1, 2, 8, 8>(p, gx, st);
 }
 
 }  // namespace segmi

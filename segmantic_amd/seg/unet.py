@@ -396,19 +396,25 @@ class UNetEngine:
                             self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
             bn.nbt += 1
 
-    def _wgrad(self, conv: _Conv, x, dy):
-        """dW, db of `conv` given its forward input x and output gradient dy."""
+    def _wgrad(self, conv: _Conv, x, dy, need_bias: bool = True):
+        """dW (and db) of `conv` given its forward input x and output gradient dy.
+
+        ``need_bias=False`` for a conv that feeds a training-mode BatchNorm: dy is then the BN
+        input gradient whose per-channel sum is identically zero (sum_v dr = gamma*invstd*(S -
+        N*S/N - (T/N)*sum xhat) = 0), so db == 0 exactly; the arena entry stays at its initial
+        zero instead of spending a pass over dy to compute rounding noise."""
         if conv.transposed:
             # dW_T[ci][co][tap]: stride-2 conv wgrad with x := dy (fine grid), dy := x (coarse)
             nbytes = ops.conv3d_wgrad_workspace(dy, x, 3, 2)
             ws = self._scratch_buf("wgrad", nbytes)
-            ops.conv3d_wgrad(dy, x, conv.gw, None, 3, 2, ws)
-            ops.bias_grad(dy, conv.gb, ws)
+            self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, dy, x, conv.gw, None, 3, 2, ws)
+            if need_bias:
+                ops.bias_grad(dy, conv.gb, ws)
         else:
             nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
             ws = self._scratch_buf("wgrad", nbytes)
-            self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw, conv.gb, conv.k,
-                        conv.stride, ws)
+            self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw,
+                        conv.gb if need_bias else None, conv.k, conv.stride, ws)
 
     def _dgrad(self, conv: _Conv, dy, dx, residual=None):
         """dx = dgrad(conv, dy) (+ residual)."""
@@ -481,7 +487,7 @@ class UNetEngine:
                 self._bn_bwd(bn, g, r, dr)
             else:
                 dr = g
-            self._wgrad(conv, xin, dr)
+            self._wgrad(conv, xin, dr, need_bias=bn is None)
             if i > 0:
                 da = self._buf(f"{pre}.da{i - 1}", xin.shape)
                 self._dgrad(conv, dr, da)
@@ -571,7 +577,7 @@ class UNetEngine:
         du = self._buf(f"{p}du", u.shape)
         self._bn_bwd(lvl["upbn"], dau, u, du)
         up = lvl["upconv"]
-        self._wgrad(up, cat, du)
+        self._wgrad(up, cat, du, need_bias=False)
         self._grads_ready(self.param_offsets[f"model.{p}2.0.conv.weight"][0])
         dcat = self._buf(f"{p}dcat", cat.shape)
         self._dgrad(up, du, dcat)
