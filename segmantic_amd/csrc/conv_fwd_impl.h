@@ -77,9 +77,23 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
     vaddr[i] = ((z * S * G::HH + y * S) * G::HW + x * S) * G::ROWB;
   }
 
+  // Weight fragments come from L2 (1 KiB coalesced per fragment).  When the whole chunk's set
+  // fits in <= 64 VGPRs it is fetched BEFORE the halo staging so its latency hides under the
+  // staging loads; otherwise the next k-step's fragments are prefetched one step ahead.
+  constexpr bool PRE = G::NSTEP * NT <= 16;
   const char* inb = (const char*)p.in;
   for (int c = 0; c < p.nchunks; ++c) {
     if (c > 0) __syncthreads();
+    const char* wb = (const char*)p.wfrag +
+                     (((int64_t)c * G::NSTEP) * p.ntiles_total + nt0) * 1024 + lane * 16;
+    frag_t wall[PRE ? G::NSTEP : 1][NT];
+    if constexpr (PRE) {
+#pragma unroll
+      for (int s = 0; s < G::NSTEP; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          wall[s][j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
+    }
     // ---- stage the halo tile of chunk c
     for (int i = tid; i < G::HD * G::HH * G::HW * G::CPR; i += 256) {
       const int v = i / G::CPR, ch = i % G::CPR;
@@ -94,8 +108,12 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
       *reinterpret_cast<frag_t*>(smem + v * G::ROWB + ch * 16) = val;
     }
     __syncthreads();
-    const char* wb = (const char*)p.wfrag +
-                     (((int64_t)c * G::NSTEP) * p.ntiles_total + nt0) * 1024 + lane * 16;
+    frag_t wnext[NT];
+    if constexpr (!PRE) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wnext[j] = *reinterpret_cast<const frag_t*>(wb + (int64_t)j * 1024);
+    }
 #pragma unroll
     for (int s = 0; s < G::NSTEP; ++s) {
       int loff;
@@ -113,9 +131,19 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
         loff = o0 * G::ROWB + (sub0 + g) * 16;
       }
       frag_t wf[NT];
+      if constexpr (PRE) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        wf[j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
+        for (int j = 0; j < NT; ++j) wf[j] = wall[s][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = wnext[j];
+        if (s + 1 < G::NSTEP) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            wnext[j] = *reinterpret_cast<const frag_t*>(
+                wb + ((int64_t)(s + 1) * p.ntiles_total + j) * 1024);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < G::VTW; ++i) {
         const frag_t a = *reinterpret_cast<const frag_t*>(smem + vaddr[i] + loff);

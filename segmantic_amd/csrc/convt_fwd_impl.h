@@ -57,19 +57,40 @@ struct ConvTGeom {
   static_assert(SPT == 2 || SPT == 4, "unsupported chunk width");
 };
 
+// all weight fragments of wave W's classes for chunk c (<= 8 k-steps): fetched before the halo
+// staging so the L2 latency hides under it
+template <typename T, int CK, int NT, int TD, int TH, int TW, int W>
+__device__ __forceinline__ void convt_wave_loadw(frag_t (&wall)[8][NT], const char* wfrag,
+                                                 const ConvTParams& p, int c, int nt0, int lane) {
+  using G = ConvTGeom<T, CK, TD, TH, TW>;
+  int idx = 0;
+#pragma unroll
+  for (int ci = 0; ci < kCtNCls[W]; ++ci) {
+    const int cls = kCtCls[W][ci];
+    const int nsteps = (ct_ntaps_c(cls) * G::SPT + 3) / 4;
+    const char* wb = wfrag + p.class_off[cls] +
+                     (((int64_t)c * nsteps) * p.ntiles_total + nt0) * 1024 + lane * 16;
+#pragma unroll
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wall[idx][j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
+      ++idx;
+    }
+  }
+}
+
 template <typename T, int CK, int NT, int TD, int TH, int TW, int W>
 __device__ __forceinline__ void convt_wave_compute(f32x4 (&acc)[3][4][NT], const char* smem,
-                                                   const int (&vaddr)[4], const char* wfrag,
-                                                   const ConvTParams& p, int c, int nt0,
-                                                   int lane, int g) {
+                                                   const int (&vaddr)[4],
+                                                   const frag_t (&wall)[8][NT], int g) {
   using G = ConvTGeom<T, CK, TD, TH, TW>;
+  int idx = 0;
 #pragma unroll
   for (int ci = 0; ci < kCtNCls[W]; ++ci) {
     const int cls = kCtCls[W][ci];
     const int ntp = ct_ntaps_c(cls);
     const int nsteps = (ntp * G::SPT + 3) / 4;
-    const char* wb = wfrag + p.class_off[cls] +
-                     (((int64_t)c * nsteps) * p.ntiles_total + nt0) * 1024 + lane * 16;
 #pragma unroll
     for (int s = 0; s < nsteps; ++s) {
       int loff;
@@ -83,16 +104,13 @@ __device__ __forceinline__ void convt_wave_compute(f32x4 (&acc)[3][4][NT], const
         const int sub0 = (4 * s) % G::SPT;
         loff = ct_tap_rowoff(cls, tap, G::HH, G::HW) * G::ROWB + (sub0 + g) * 16;
       }
-      frag_t wf[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        wf[j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
 #pragma unroll
       for (int vt = 0; vt < 4; ++vt) {
         const frag_t a = *reinterpret_cast<const frag_t*>(smem + vaddr[vt] + loff);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[ci][vt][j] = mma16<T>(wf[j], a, acc[ci][vt][j]);
+        for (int j = 0; j < NT; ++j) acc[ci][vt][j] = mma16<T>(wall[idx][j], a, acc[ci][vt][j]);
       }
+      ++idx;
     }
   }
 }
@@ -181,6 +199,11 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
   const char* wfrag = (const char*)p.wfrag;
   for (int c = 0; c < p.nchunks; ++c) {
     if (c > 0) __syncthreads();
+    frag_t wall[8][NT];
+    if (wave == 0) convt_wave_loadw<T, CK, NT, TD, TH, TW, 0>(wall, wfrag, p, c, nt0, lane);
+    else if (wave == 1) convt_wave_loadw<T, CK, NT, TD, TH, TW, 1>(wall, wfrag, p, c, nt0, lane);
+    else if (wave == 2) convt_wave_loadw<T, CK, NT, TD, TH, TW, 2>(wall, wfrag, p, c, nt0, lane);
+    else convt_wave_loadw<T, CK, NT, TD, TH, TW, 3>(wall, wfrag, p, c, nt0, lane);
     for (int i = tid; i < G::HD * G::HH * G::HW * G::CPR; i += 256) {
       const int v = i / G::CPR, ch = i % G::CPR;
       const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
@@ -193,10 +216,10 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
       *reinterpret_cast<frag_t*>(smem + v * G::ROWB + ch * 16) = val;
     }
     __syncthreads();
-    if (wave == 0) convt_wave_compute<T, CK, NT, TD, TH, TW, 0>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
-    else if (wave == 1) convt_wave_compute<T, CK, NT, TD, TH, TW, 1>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
-    else if (wave == 2) convt_wave_compute<T, CK, NT, TD, TH, TW, 2>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
-    else convt_wave_compute<T, CK, NT, TD, TH, TW, 3>(acc, smem, vaddr, wfrag, p, c, nt0, lane, g);
+    if (wave == 0) convt_wave_compute<T, CK, NT, TD, TH, TW, 0>(acc, smem, vaddr, wall, g);
+    else if (wave == 1) convt_wave_compute<T, CK, NT, TD, TH, TW, 1>(acc, smem, vaddr, wall, g);
+    else if (wave == 2) convt_wave_compute<T, CK, NT, TD, TH, TW, 2>(acc, smem, vaddr, wall, g);
+    else convt_wave_compute<T, CK, NT, TD, TH, TW, 3>(acc, smem, vaddr, wall, g);
   }
 
   f32x4 ssum[NT], ssq[NT];

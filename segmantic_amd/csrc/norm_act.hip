@@ -6,13 +6,21 @@
 
 namespace segmi {
 
-constexpr int kStatVox = 4096;  // voxels per workgroup in the reduction kernels
+// voxels per workgroup in the reduction kernels: 4096 for large tensors, fewer (>= 64) for small
+// ones so that at least ~512 workgroups exist (deep 8^3 x 256-channel layers)
+static inline int stat_vox(int64_t nvox) {
+  int v = 4096;
+  while (v > 64 && nvox / v < 512) v >>= 1;
+  return v;
+}
 constexpr int kCollapseBlocks = 64;
 // rows reserved behind every caller-visible partial buffer for the f64 stage-1 result:
 // 64 blocks x width doubles = 128 rows of `width` floats (+1 for 8-byte alignment)
 constexpr int kReserveRows = 2 * kCollapseBlocks + 1;
 
-int bn_stats_rows_for(const segmi_act* x) { return (int)cdiv64(act_voxels(x), kStatVox); }
+int bn_stats_rows_for(const segmi_act* x) {
+  return (int)cdiv64(act_voxels(x), stat_vox(act_voxels(x)));
+}
 int stats_reserve_rows() { return kReserveRows; }
 
 template <typename T, int VEC>
@@ -39,7 +47,7 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[VEC]) {
 struct EwParams {
   const void* x; const void* y; const void* r; void* o;
   int64_t nvox;
-  int c, ldx, ldy, ldr, ldo;
+  int c, ldx, ldy, ldr, ldo, vpw;
   const float* p0; const float* p1; const float* p2; const float* p3; const float* alpha;
   const float* coef;
   float* out_partials;
@@ -53,8 +61,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(EwParams p) {
   const int vpp = 256 / cg > 0 ? 256 / cg : 1;  // voxels per pass
   const int tid = threadIdx.x;
   const int my_cg = tid % cg, my_v = tid / cg;
-  const int64_t v0 = (int64_t)blockIdx.x * kStatVox;
-  const int64_t v1 = v0 + kStatVox < p.nvox ? v0 + kStatVox : p.nvox;
+  const int64_t v0 = (int64_t)blockIdx.x * p.vpw;
+  const int64_t v1 = v0 + p.vpw < p.nvox ? v0 + p.vpw : p.nvox;
   const T* x = (const T*)p.x;
   float s[VEC], q[VEC];
 #pragma unroll
@@ -83,8 +91,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(EwParams p) {
 // wide-channel fallback (c/VEC > 256): one thread per channel loop
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_wide_kernel(EwParams p) {
-  const int64_t v0 = (int64_t)blockIdx.x * kStatVox;
-  const int64_t v1 = v0 + kStatVox < p.nvox ? v0 + kStatVox : p.nvox;
+  const int64_t v0 = (int64_t)blockIdx.x * p.vpw;
+  const int64_t v1 = v0 + p.vpw < p.nvox ? v0 + p.vpw : p.nvox;
   const T* x = (const T*)p.x;
   for (int ch = threadIdx.x; ch < p.c; ch += 256) {
     float s = 0.f, q = 0.f;
@@ -105,6 +113,7 @@ static inline bool vec4_ok(const segmi_act* a, int dtype) {
 int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st) {
   EwParams p{};
   p.x = x->data; p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld; p.out_partials = partials;
+  p.vpw = stat_vox(p.nvox);
   const int rows = bn_stats_rows_for(x);
   const bool v4 = vec4_ok(x, dtype) && x->c / 4 <= 256;
   if (v4) {
@@ -261,8 +270,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
   const int vpp = 256 / cg > 0 ? 256 / cg : 1;
   const int tid = threadIdx.x;
   const int my_cg = tid % cg, my_v = tid / cg;
-  const int64_t v0 = (int64_t)blockIdx.x * kStatVox;
-  const int64_t v1 = v0 + kStatVox < p.nvox ? v0 + kStatVox : p.nvox;
+  const int64_t v0 = (int64_t)blockIdx.x * p.vpw;
+  const int64_t v1 = v0 + p.vpw < p.nvox ? v0 + p.vpw : p.nvox;
   const T* x = (const T*)p.x;
   const T* dy = (const T*)p.y;
   const bool has_alpha = p.alpha != nullptr;
@@ -532,6 +541,7 @@ int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
   p.x = x->data; p.y = dy->data; p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld;
   p.ldy = dy->ld; p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha;
   p.out_partials = red_partials;
+  p.vpw = stat_vox(p.nvox);
   const bool v4 = vec4_ok(x, dtype) && vec4_ok(dy, dtype);
   const int rows = bn_stats_rows_for(x);
   DISPATCH_TV(bn_act_bwd_reduce_kernel, dtype, v4, rows, 0, (hipStream_t)stream, p);
