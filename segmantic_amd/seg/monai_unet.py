@@ -8,8 +8,6 @@ and top-k checkpointing of Lightning (``:503-541``) are re-stated in ~100 lines 
 ``mixed_precision=True`` selects bf16 storage with f32 accumulation (the reference's
 ``precision=16`` AMP, ``:533``); ``False`` selects the exact-f32 MFMA path used for parity.
 """
-from __future__ import annotations
-
 import json
 import os
 import re

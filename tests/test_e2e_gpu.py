@@ -1,0 +1,198 @@
+"""GPU end-to-end tests: committed golden vectors, sliding-window inference through the real
+network vs the oracle, image ops (drop-in ``processing`` API), and the
+``segmantic-unet train-config`` / ``predict`` surface on a tiny synthetic NIfTI dataset."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle.sliding_ref import ref_sliding_window_inference  # noqa: E402
+from oracle.unet_ref import RefUNet, deterministic_fill_, ref_dice_loss, synthetic_batch  # noqa: E402
+from segmantic_amd.seg.inferers import SlidingWindowInferer, sliding_window_inference  # noqa: E402
+from segmantic_amd.seg.monai_unet import Net  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(golden_dir / "oracle_goldens.npz", allow_pickle=False)
+
+
+def pair(k, channels, strides, cin=1):
+    ref = deterministic_fill_(RefUNet(3, cin, k, channels, strides), 0)
+    net = Net(num_classes=k, num_channels=cin, channels=channels, strides=strides)
+    net.load_state_dict({"_model." + kk: v.clone() for kk, v in ref.state_dict().items()})
+    return ref, net.to(DEV)
+
+
+def test_hip_path_reproduces_committed_goldens(gold):
+    ref, net = pair(3, (4, 8, 16), (2, 2))
+    img, lab = synthetic_batch(2, 16, 3, seed=1)
+    net.train()
+    res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+    torch.cuda.synchronize()
+    logits = net._engine._bufs["logits.t"].float().cpu().permute(0, 4, 1, 2, 3).numpy()
+    g = gold["tiny_logits"]
+    assert np.abs(logits - g).max() / np.abs(g).max() < 2e-4            # 1e-3 gate
+    assert abs(float(res["loss"].cpu()) - float(gold["tiny_loss"])) < 1e-4 * float(gold["tiny_loss"])
+    sd = net._model.state_dict()
+    for i, k in enumerate(gold["tiny_sel_keys"]):
+        a = gold[f"tiny_adam_{i}"]
+        # Adam's first step is lr * sign(g): equal except where g is rounding noise (sign may flip)
+        close = np.abs(sd[str(k)].cpu().numpy() - a) < 3e-6
+        assert close.mean() > 0.99, (str(k), close.mean())
+    np.testing.assert_allclose(sd["model.0.conv.unit0.adn.N.running_mean"].cpu().numpy(), gold["tiny_running_mean"], atol=1e-5)
+    # eval mode (folded BN) against the golden eval logits
+    _, net2 = pair(3, (4, 8, 16), (2, 2))
+    net2.eval()
+    with torch.no_grad():
+        y = net2(img.to(DEV)).float().cpu().numpy()
+    ge = gold["tiny_eval_logits"]
+    assert np.abs(y - ge).max() / np.abs(ge).max() < 2e-4
+    # full default net, K=3, 32^3 (BASELINE config 1 shape)
+    _, net3 = pair(3, (16, 32, 64, 128, 256), (2, 2, 2, 2))
+    img32, lab32 = synthetic_batch(1, 32, 3, seed=2)
+    net3.train()
+    with torch.no_grad():
+        y = net3(img32.to(DEV)).float().cpu()
+    blk = gold["full_logits_block"]
+    assert np.abs(y[0, :, :8, :8, :8].numpy() - blk).max() / np.abs(blk).max() < 2e-4
+    assert abs(float(y.double().abs().sum()) - float(gold["full_logits_abs_sum"])) < 1e-4 * float(gold["full_logits_abs_sum"])
+
+
+@pytest.mark.parametrize("overlap,mode", [(0.25, "constant"), (0.5, "constant"), (0.5, "gaussian")])
+def test_sliding_window_through_the_network_vs_oracle(overlap, mode):
+    ref, net = pair(4, (16, 32, 64), (2, 2))
+    ref.eval(); net.eval()
+    img, _ = synthetic_batch(1, 40, 4, seed=4)
+    img = img[..., :40, :36, :44]
+    with torch.no_grad():
+        o_ref, _, wins = ref_sliding_window_inference(img, (16, 16, 16), 4, ref, overlap, mode)
+        res = sliding_window_inference(img.to(DEV), (16, 16, 16), 4, net, overlap, mode, return_labels=True)
+    torch.cuda.synchronize()
+    got = res.logits.cpu()
+    assert got.shape == o_ref.shape
+    assert float((got - o_ref).abs().max() / o_ref.abs().max()) < 2e-4
+    lab_ref = torch.argmax(o_ref, 1)
+    mism = res.labels.cpu().long()[:, 0] != lab_ref
+    if mism.any():    # only near-ties may flip
+        top2 = torch.topk(o_ref, 2, dim=1).values
+        assert float((top2[:, 0] - top2[:, 1])[mism].max()) < 1e-4 * float(o_ref.abs().max())
+    assert float(mism.float().mean()) < 1e-3
+    # the label volume is bit-exact w.r.t. OUR logits (fused argmax == torch.argmax)
+    assert torch.equal(res.labels.cpu().long()[:, 0], torch.argmax(got, 1))
+
+
+def test_sliding_window_image_smaller_than_roi_and_inferer_class():
+    ref, net = pair(2, (16, 32), (2,))
+    ref.eval(); net.eval()
+    img, _ = synthetic_batch(1, 16, 2, seed=6)
+    img = img[..., :12, :16, :10]
+    with torch.no_grad():
+        o_ref, _, _ = ref_sliding_window_inference(img, (16, 16, 16), 4, ref, 0.25)
+        got = SlidingWindowInferer(roi_size=(16, 16, 16), sw_batch_size=4)(img.to(DEV), net)
+    assert got.shape == o_ref.shape
+    assert float((got.cpu() - o_ref).abs().max() / o_ref.abs().max()) < 2e-4
+
+
+def test_full_size_properties_128_bf16():
+    """BASELINE-size checks through size-independent properties: batch items are independent in
+    eval mode, sliding-window of a single-window volume equals the plain forward, logits finite."""
+    net = Net(num_classes=16).to(DEV).eval()
+    net.mixed_precision = True
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 1, 128, 128, 128), generator=g).to(DEV)
+    with torch.no_grad():
+        y = net(x).float().clone()
+        y0 = net(x[:1].contiguous()).float().clone()
+        sw = sliding_window_inference(x[:1].contiguous(), (128, 128, 128), 4, net)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    assert torch.equal(y[:1], y0)                                  # deterministic, batch independent
+    assert float((sw - y0).abs().max()) < 1e-6 * float(y0.abs().max()) + 1e-6
+    net.train()
+    img, lab = x, torch.randint(0, 16, (2, 1, 128, 128, 128), generator=g).float().to(DEV)
+    l1 = float(net.training_step({"image": img, "label": lab})["loss"].cpu())
+    for _ in range(5):
+        l2 = float(net.training_step({"image": img, "label": lab})["loss"].cpu())
+    assert np.isfinite(l1) and l2 < l1                              # the optimiser descends
+
+
+def test_processing_dropin_geometry_and_values():
+    """reference tests/image/test_image.py:33-52 restated on the HIP resample path"""
+    from oracle.resample_ref import ref_resample_grid
+    from segmantic_amd.image import processing
+    lf = processing.make_image(shape=(5, 5, 5), spacing=(0.5, 0.6, 0.7))
+    for i in range(5):
+        lf.data[i] = i
+    spacing = [s / 2.0 for s in lf.GetSpacing()]
+    res = processing.resample(lf, target_spacing=spacing)
+    assert list(res.GetSize()) == [2 * s for s in lf.GetSize()]
+    ref_img = processing.make_image((12, 10, 7), spacing, pixel_type=processing.sitkUInt16)
+    ref_img.SetOrigin([1.3, -2.1, 0.75])
+    out = processing.resample_to_ref(lf, ref_img, nearest=True)
+    assert list(out.GetSize()) == list(ref_img.GetSize()) and list(out.GetSpacing()) == list(ref_img.GetSpacing())
+    exp = ref_resample_grid(lf.numpy(), lf.GetSpacing(), (0, 0, 0), np.eye(3), (12, 10, 7), spacing, (1.3, -2.1, 0.75), np.eye(3), True)
+    assert np.array_equal(out.numpy(), exp)
+    # pad o crop_center identity, extract_slices (test_image.py:7-30)
+    sl = processing.extract_slices(lf, axis=2)
+    assert len(sl) == 5 and sl[3].GetSize() == (5, 5) and int(sl[3].data[0, 0]) == 3
+    c = processing.crop_center(lf, target_size=(5, 5, 1))
+    assert c.GetSize()[2] == 1
+    # rotation about z by 90 degrees through apply_transform
+    f = processing.Image(np.random.default_rng(0).standard_normal((6, 8, 8)).astype(np.float32))
+    T = np.eye(4); T[:2, :2] = [[0, -1], [1, 0]]; T[:3, 3] = [7, 0, 0]
+    rot = processing.apply_transform(f, f, T, nearest=False)
+    exp = ref_resample_grid(f.numpy(), (1, 1, 1), (0, 0, 0), np.eye(3), (8, 8, 6), (1, 1, 1), (0, 0, 0), np.eye(3), False, transform=T)
+    np.testing.assert_allclose(rot.numpy(), exp, atol=1e-6)
+
+
+def _write_dataset(root: Path, n=4, size=24, classes=3):
+    from segmantic_amd.data.nifti import write_nifti
+    (root / "image").mkdir(parents=True)
+    (root / "label").mkdir()
+    A = np.diag([1.0, 1.0, 1.0, 1.0])
+    for i in range(n):
+        img, lab = synthetic_batch(1, size, classes, seed=20 + i)
+        write_nifti(root / "image" / f"c{i}.nii.gz", (img[0, 0].numpy() * 100 + 300).astype(np.float32).transpose(2, 1, 0), A)
+        write_nifti(root / "label" / f"c{i}.nii.gz", lab[0, 0].numpy().astype(np.uint8).transpose(2, 1, 0), A)
+    dl = {"labels": {"1": "a", "2": "b"},
+          "training": [{"image": f"image/c{i}.nii.gz", "label": f"label/c{i}.nii.gz"} for i in range(n - 1)],
+          "validation": [{"image": f"image/c{n - 1}.nii.gz", "label": f"label/c{n - 1}.nii.gz"}],
+          "test": [{"image": f"image/c{n - 1}.nii.gz", "label": f"label/c{n - 1}.nii.gz"}]}
+    (root / "dataset.json").write_text(json.dumps(dl))
+    return root / "dataset.json"
+
+
+def test_cli_train_config_then_predict(tmp_path):
+    """BASELINE config 0 surface (segmantic-unet train-config / predict) on the GPU path."""
+    import yaml
+    from typer.testing import CliRunner
+
+    from segmantic_amd.commands.monai_unet_cli import app
+    datalist = _write_dataset(tmp_path / "data")
+    out = tmp_path / "results"
+    cfg = {"datalist": str(datalist), "output_dir": str(out), "spatial_size": [16, 16, 16],
+           "channels": [16, 32, 64], "strides": [2, 2], "max_epochs": 3, "mixed_precision": False,
+           "num_samples": 2, "gpu_ids": [0], "optimizer": {"optimizer": "Adam", "lr": 1e-3, "amsgrad": False}}
+    (tmp_path / "cfg.yml").write_text(yaml.safe_dump(cfg))
+    runner = CliRunner()
+    res = runner.invoke(app, ["train-config", "-c", str(tmp_path / "cfg.yml")])
+    assert res.exit_code == 0, (res.output, res.exception)
+    ckpts = sorted(out.glob("epoch=*-val_loss=*-val_dice=*.ckpt"))
+    assert 1 <= len(ckpts) <= 3
+    assert (out / "Dataset.json").exists() and (out / "logs" / "metrics.csv").exists()
+    ck = torch.load(ckpts[-1], map_location="cpu", weights_only=False)
+    assert ck["hyper_parameters"]["num_classes"] == 3 and "_model.model.0.conv.unit0.conv.weight" in ck["state_dict"]
+    res = runner.invoke(app, ["predict", "-d", str(datalist), "-m", str(ckpts[-1]), "-r", str(tmp_path / "pred"), "--gpu-ids", "0"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    from segmantic_amd.data.nifti import read_nifti
+    pred, _ = read_nifti(tmp_path / "pred" / "c3.nii.gz")
+    assert pred.shape == (24, 24, 24) and pred.max() <= 2
+    assert (tmp_path / "pred" / f"mean_dice_{ckpts[-1].stem}_generalized_score.txt").exists()
