@@ -401,8 +401,17 @@ def predict(
         settings = json.loads(settings_json.read_text())
         net = Net.load_from_checkpoint(f"{model_file}", **settings)
     else:
-        net = Net.load_from_checkpoint(f"{model_file}", channels=channels, strides=strides,
-                                       dropout=dropout)
+        # The reference always overrides the checkpoint's hparams with these arguments, which
+        # makes its CLI unable to load non-default architectures; here an argument left at its
+        # default does not override what the checkpoint recorded.
+        over = {}
+        if tuple(channels) != (16, 32, 64, 128, 256):
+            over["channels"] = channels
+        if tuple(strides) != (2, 2, 2, 2):
+            over["strides"] = strides
+        if dropout != 0.0:
+            over["dropout"] = dropout
+        net = Net.load_from_checkpoint(f"{model_file}", **over)
     num_classes = net.num_classes
     net.freeze()
     net.eval()

@@ -165,8 +165,11 @@ def _write_dataset(root: Path, n=4, size=24, classes=3):
     dl = {"labels": {"1": "a", "2": "b"},
           "training": [{"image": f"image/c{i}.nii.gz", "label": f"label/c{i}.nii.gz"} for i in range(n - 1)],
           "validation": [{"image": f"image/c{n - 1}.nii.gz", "label": f"label/c{n - 1}.nii.gz"}],
-          "test": [{"image": f"image/c{n - 1}.nii.gz", "label": f"label/c{n - 1}.nii.gz"}]}
+          "test": [f"image/c{n - 1}.nii.gz"]}
     (root / "dataset.json").write_text(json.dumps(dl))
+    # predict reads the "test" section through the decathlon loader, which takes image/label dicts
+    dl["test"] = [{"image": f"image/c{n - 1}.nii.gz", "label": f"label/c{n - 1}.nii.gz"}]
+    (root / "predict.json").write_text(json.dumps(dl))
     return root / "dataset.json"
 
 
@@ -190,7 +193,7 @@ def test_cli_train_config_then_predict(tmp_path):
     assert (out / "Dataset.json").exists() and (out / "logs" / "metrics.csv").exists()
     ck = torch.load(ckpts[-1], map_location="cpu", weights_only=False)
     assert ck["hyper_parameters"]["num_classes"] == 3 and "_model.model.0.conv.unit0.conv.weight" in ck["state_dict"]
-    res = runner.invoke(app, ["predict", "-d", str(datalist), "-m", str(ckpts[-1]), "-r", str(tmp_path / "pred"), "--gpu-ids", "0"])
+    res = runner.invoke(app, ["predict", "-d", str(datalist.parent / "predict.json"), "-m", str(ckpts[-1]), "-r", str(tmp_path / "pred"), "--gpu-ids", "0"])
     assert res.exit_code == 0, (res.output, res.exception)
     from segmantic_amd.data.nifti import read_nifti
     pred, _ = read_nifti(tmp_path / "pred" / "c3.nii.gz")
