@@ -2,6 +2,7 @@
 // kernels used when a channel count is not a multiple of 16 (first layer Cin=1, K=3 heads,
 // tiny test networks).
 #include "conv_fwd_impl.h"
+#include "conv_ring_impl.h"
 #include "convt_fwd_impl.h"
 
 namespace segmi {
@@ -128,9 +129,12 @@ extern "C" {
 
 int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                             int stride) {
-  (void)dtype; (void)ksize;
   if (!in || !out) return 0;
-  if (mfma_ok(in->c, out->c)) return conv_mfma_rows(out, stride) + stats_reserve_rows();
+  if (mfma_ok(in->c, out->c)) {
+    if (conv_ring_ok(dtype, in->c, ksize, stride, out))
+      return conv_ring_rows(dtype, in->c, out) + stats_reserve_rows();
+    return conv_mfma_rows(out, stride) + stats_reserve_rows();
+  }
   return bn_stats_rows_for(out) + stats_reserve_rows();
 }
 

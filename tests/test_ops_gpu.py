@@ -53,6 +53,9 @@ CONV_CASES = [
     (64, 64, 3, 1, (4, 4, 8), 1),
     (128, 256, 1, 1, (4, 4, 4), 2),
     (16, 48, 3, 1, (5, 9, 17), 1),
+    (16, 16, 3, 1, (16, 64, 128), 4),    # z-marching ring kernel, 256 columns, 1 segment
+    (16, 16, 3, 1, (33, 60, 120), 2),    # ring kernel, 2 z-segments, ragged extents
+    (32, 32, 3, 1, (33, 60, 120), 2),    # ring kernel, CK=32, two output tiles
     (1, 16, 3, 2, (12, 12, 12), 2),   # direct kernel (first layer)
     (16, 3, 3, 1, (6, 7, 9), 1),      # direct kernel (K=3 head)
     (4, 8, 3, 2, (9, 9, 9), 1),       # direct kernel, odd extents
@@ -109,6 +112,29 @@ def test_conv3d_epilogue_prelu_residual_and_views(dtype):
     torch.cuda.synchronize()
     assert relerr(from_ndhwc(big_out[..., 16:32]), ref) < tol(dtype)
     assert float(big_out[..., :16].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_ring_kernel_epilogue(dtype):
+    """ring kernel (full-resolution shapes): PReLU + prefetched residual + fused statistics"""
+    n, c, sp = 4, 16, (16, 64, 128)
+    x, r = rnd((n, c) + sp, 15), rnd((n, c) + sp, 16)
+    w, b = rnd((c, c, 3, 3, 3), 17, 0.05), rnd((c,), 18, 0.1)
+    raw = F.conv3d(q(x, dtype), q(w, dtype), b, padding=1)
+    ref = F.prelu(raw, torch.tensor([0.3])) + q(r, dtype)
+    xd, rd = to_ndhwc(x, dtype), to_ndhwc(r, dtype)
+    yd = torch.empty_like(xd)
+    wd = w.to(DEV)
+    packed = ops.wpack(dtype, 0, wd, c, c, 3)
+    rows = ops.conv3d_stats_rows(xd, yd, 3, 1)
+    stats = torch.zeros((rows, 2, c), device=DEV)
+    ops.conv3d_fwd(xd, yd, packed, None, 0, b.to(DEV), 3, 1, prelu_alpha=torch.tensor([0.3], device=DEV),
+                   residual=rd, stats=stats)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(yd), ref) < tol(dtype)
+    ssum = stats[:, 0].double().sum(0).cpu()
+    assert float((ssum - raw.double().sum((0, 2, 3, 4))).abs().max()) / (raw.numel() / c) < \
+        (1e-5 if dtype == torch.float32 else 2e-2) * float(raw.abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
