@@ -138,8 +138,9 @@ int segmi_ndhwc_to_nchw(int src_dtype, const segmi_act* src, float* dst, void* s
 
 /* ---------------------------------------------------------------- loss + optimiser ----- */
 /* MONAI DiceLoss(to_onehot_y=True, softmax=True), monai_unet.py:128,344.
- * labels: f32[n*d*h*w] integer-valued class ids.  partials f32[n][chunks][3][k];
- * coef f32[n][2][k] receives the backward coefficients; loss f32[1]. */
+ * labels: f32[n*d*h*w] integer-valued class ids.  partials f32[segmi_dice_chunks()][n][3][k]
+ * (the chunk count includes a scratch tail); coef f32[n][2][k] receives the backward
+ * coefficients; loss f32[1]. */
 int segmi_dice_chunks(const segmi_act* logits);
 int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labels,
                            float* partials, float* coef, float* loss, float smooth_nr,

@@ -8,6 +8,8 @@ namespace segmi {
 
 constexpr int kDiceVox = 8192;  // voxels per workgroup
 
+int collapse_rows_into(const float* partials, int rows, int width, double* out, hipStream_t st);
+
 struct DiceParams {
   const void* logits;
   const float* labels;
@@ -96,12 +98,12 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
     const int which = tid / p.k, j = tid % p.k;
     const float s = red[0][which * KMAX + j] + red[1][which * KMAX + j] +
                     red[2][which * KMAX + j] + red[3][which * KMAX + j];
-    p.partials[(((int64_t)n * p.chunks + chunk) * 3 + which) * p.k + j] = s;
+    p.partials[(((int64_t)chunk * p.n + n) * 3 + which) * p.k + j] = s;   // [chunk][n][3][k]
   }
 }
 
-// one block: per (n,k) sums in f64, loss + backward coefficients
-__global__ __launch_bounds__(256) void dice_finalize_kernel(const float* __restrict__ partials,
+// one block: per (n,k) sums of the collapsed rows (f64), loss + backward coefficients
+__global__ __launch_bounds__(256) void dice_finalize_kernel(const double* __restrict__ partials,
                                                             int n, int k, int chunks,
                                                             float smooth_nr, float smooth_dr,
                                                             float* coef, float* loss) {
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(256) void dice_finalize_kernel(const float* __restr
     const int b = o / k, j = o % k;
     double I = 0.0, P = 0.0, Tt = 0.0;
     for (int c = 0; c < chunks; ++c) {
-      const float* q = partials + (((int64_t)b * chunks + c) * 3) * k + j;
-      I += (double)q[0]; P += (double)q[k]; Tt += (double)q[2 * k];
+      const double* q = partials + (((int64_t)c * n + b) * 3) * k + j;
+      I += q[0]; P += q[k]; Tt += q[2 * k];
     }
     // f32 arithmetic as the reference does on the reduced sums
     const float If = (float)I, Df = (float)Tt + (float)P;
@@ -269,9 +271,15 @@ using namespace segmi;
 
 extern "C" {
 
+static inline int dice_real_chunks(const segmi_act* logits) {
+  return (int)cdiv64((int64_t)logits->d * logits->h * logits->w, kDiceVox);
+}
+
+// chunks the caller must allocate: the real ones + a 129-chunk tail that holds the f64 stage-1
+// reduction (64 x [n][3][k] doubles), same scheme as the *_stats_rows() queries
 int segmi_dice_chunks(const segmi_act* logits) {
   if (!logits) return 0;
-  return (int)cdiv64((int64_t)logits->d * logits->h * logits->w, kDiceVox);
+  return dice_real_chunks(logits) + 129;
 }
 
 int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labels,
@@ -283,13 +291,18 @@ int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labe
   p.logits = logits->data; p.labels = labels; p.partials = partials;
   p.n = logits->n; p.k = logits->c; p.ld = logits->ld;
   p.vox = (int64_t)logits->d * logits->h * logits->w;
-  p.chunks = segmi_dice_chunks(logits);
+  p.chunks = dice_real_chunks(logits);
   hipStream_t st = (hipStream_t)stream;
-  const int rc = dtype == SEGMI_F32 ? dice_dispatch<float>(true, p, st)
-                                    : dice_dispatch<bf16_t>(true, p, st);
+  int rc = dtype == SEGMI_F32 ? dice_dispatch<float>(true, p, st)
+                              : dice_dispatch<bf16_t>(true, p, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(dice_finalize_kernel, 1, 256, 0, st, (const float*)partials, p.n, p.k,
-                     p.chunks, smooth_nr, smooth_dr, coef, loss);
+  const int width = p.n * 3 * p.k;
+  uintptr_t tail = (uintptr_t)(partials + (int64_t)p.chunks * width);
+  double* col = (double*)((tail + 7) & ~(uintptr_t)7);
+  rc = collapse_rows_into(partials, p.chunks, width, col, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dice_finalize_kernel, 1, 256, 0, st, (const double*)col, p.n, p.k, 64,
+                     smooth_nr, smooth_dr, coef, loss);
   SEGMI_LAUNCH_CHECK("softmax_dice_fwd(finalize)");
   return SEGMI_OK;
 }
@@ -306,7 +319,7 @@ int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labe
   p.logits = logits->data; p.labels = labels; p.coef = coef; p.dlogits = dlogits->data;
   p.n = logits->n; p.k = logits->c; p.ld = logits->ld; p.ldd = dlogits->ld;
   p.vox = (int64_t)logits->d * logits->h * logits->w;
-  p.chunks = segmi_dice_chunks(logits);
+  p.chunks = dice_real_chunks(logits);
   p.grad_scale = grad_scale;
   hipStream_t st = (hipStream_t)stream;
   return dtype == SEGMI_F32 ? dice_dispatch<float>(false, p, st)

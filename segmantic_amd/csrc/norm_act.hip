@@ -160,6 +160,12 @@ static inline double* collapse_scratch(const float* partials, int real_rows, int
   uintptr_t p = (uintptr_t)(partials + (int64_t)real_rows * width);
   return (double*)((p + 7) & ~(uintptr_t)7);
 }
+// shared with loss_optim.hip / wgrad.hip: collapse [rows][width] f32 into `out` [64][width] f64
+int collapse_rows_into(const float* partials, int rows, int width, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(collapse_rows_kernel, kCollapseBlocks, 256, 0, st, partials, rows, width, out);
+  SEGMI_LAUNCH_CHECK("collapse_rows");
+  return SEGMI_OK;
+}
 static int collapse_launch(const float* partials, int real_rows, int width, hipStream_t st) {
   hipLaunchKernelGGL(collapse_rows_kernel, kCollapseBlocks, 256, 0, st, partials, real_rows, width,
                      collapse_scratch(partials, real_rows, width));

@@ -7,6 +7,7 @@ int wgrad_mfma_f32(const WgradParams& p, int ksize, int stride, int ct, int gx, 
 int wgrad_mfma_bf16(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
 int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
 int bn_stats_rows_for(const segmi_act* x);
+int collapse_rows_into(const float* partials, int rows, int width, double* out, hipStream_t st);
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_wgrad_slabs(const segmi_act* dy);
 int conv_small_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* partials,
@@ -55,44 +56,37 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgDirectParams p) {
   }
 }
 
-// out[e] = sum_b partials[b][e], fixed order, f64 accumulate
+// out[gy][e] = sum over the slabs of group gy (blockIdx.y) of partials[b][e]; fixed order, f64
+// accumulate.  Many slabs are reduced in two passes (16 groups, then the 16 group sums) so that
+// the column sum has enough parallelism instead of one thread walking 1024 slabs.
+constexpr int kSlabGroups = 16;
 __global__ void slab_reduce_kernel(const float* __restrict__ partials, int nslab, int64_t n,
                                    float* __restrict__ out) {
+  const int per = (nslab + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per;
+  const int b1 = b0 + per < nslab ? b0 + per : nslab;
   for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int b = 0;
-    for (; b + 3 < nslab; b += 4) {
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
       a0 += (double)partials[(int64_t)b * n + e];
       a1 += (double)partials[(int64_t)(b + 1) * n + e];
       a2 += (double)partials[(int64_t)(b + 2) * n + e];
       a3 += (double)partials[(int64_t)(b + 3) * n + e];
     }
-    for (; b < nslab; ++b) a0 += (double)partials[(int64_t)b * n + e];
-    out[e] = (float)((a0 + a1) + (a2 + a3));
+    for (; b < b1; ++b) a0 += (double)partials[(int64_t)b * n + e];
+    out[(int64_t)blockIdx.y * n + e] = (float)((a0 + a1) + (a2 + a3));
   }
 }
 
-// stats partials [rows][2][c] -> db[c] = sum of the "sum" rows (f64, fixed order)
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ partials,
-                                                          int rows, int c, float* __restrict__ db) {
-  __shared__ double red[256];
-  const int cp = c < 256 ? c : 256;
-  const int parts = 256 / cp;
-  const int tid = threadIdx.x;
-  for (int c0 = 0; c0 < c; c0 += cp) {
-    const int ch = c0 + tid % cp, part = tid / cp;
-    double s = 0.0;
-    if (part < parts && ch < c)
-      for (int r = part; r < rows; r += parts) s += (double)partials[((int64_t)r * 2) * c + ch];
-    red[tid] = s;
-    __syncthreads();
-    if (tid < cp && c0 + tid < c) {
-      double t = 0.0;
-      for (int pi = 0; pi < parts; ++pi) t += red[pi * cp + tid];
-      db[c0 + tid] = (float)t;
-    }
-    __syncthreads();
-  }
+// collapsed stats [64][2][c] f64 -> db[c] = sum of the "sum" rows (fixed order)
+__global__ void bias_reduce_kernel(const double* __restrict__ col, int rows, int c,
+                                   float* __restrict__ db) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double acc = 0.0;
+  for (int r = 0; r < rows; ++r) acc += col[((int64_t)r * 2) * c + ch];
+  db[ch] = (float)acc;
 }
 
 static inline bool aligned_rows(const segmi_act* a, int dtype) {
@@ -131,8 +125,8 @@ int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_
   if (!x || !dy) return 0;
   const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
   const int slabs = wg_slabs(dtype, x, dy, ksize, stride);
-  const int64_t bias = (int64_t)bn_stats_rows_for(dy) * 2 * dy->c * 4;
-  return align256(slabs * nout * 4) + align256(bias);
+  const int64_t bias = ((int64_t)bn_stats_rows_for(dy) + 129) * 2 * dy->c * 4;  // + f64 collapse tail
+  return align256(slabs * nout * 4) + align256((int64_t)kSlabGroups * nout * 4) + align256(bias);
 }
 
 int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream) {
@@ -140,8 +134,12 @@ int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, 
   hipStream_t st = (hipStream_t)stream;
   int rc = bn_stats_launch(dtype, dy, (float*)workspace, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(bias_reduce_kernel, 1, 256, 0, st, (const float*)workspace,
-                     bn_stats_rows_for(dy), dy->c, db);
+  const int rows = bn_stats_rows_for(dy), width = 2 * dy->c;
+  uintptr_t tail = (uintptr_t)((float*)workspace + (int64_t)rows * width);
+  double* col = (double*)((tail + 7) & ~(uintptr_t)7);
+  rc = collapse_rows_into((const float*)workspace, rows, width, col, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bias_reduce_kernel, cdiv(dy->c, 64), 64, 0, st, (const double*)col, 64, dy->c, db);
   SEGMI_LAUNCH_CHECK("bias_grad");
   return SEGMI_OK;
 }
@@ -184,10 +182,19 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
     SEGMI_LAUNCH_CHECK("conv3d_wgrad(direct)");
   }
   const int rb = (int)(cdiv64(nout, 256) > 2048 ? 2048 : cdiv64(nout, 256));
-  hipLaunchKernelGGL(slab_reduce_kernel, rb, 256, 0, st, (const float*)partials, slabs, nout, dw);
+  float* gsum = (float*)((char*)workspace + align256((int64_t)slabs * nout * 4));
+  if (slabs > 2 * kSlabGroups) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb, kSlabGroups), 256, 0, st, (const float*)partials,
+                       slabs, nout, gsum);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb, 1), 256, 0, st, (const float*)gsum, kSlabGroups,
+                       nout, dw);
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb, 1), 256, 0, st, (const float*)partials, slabs,
+                       nout, dw);
+  }
   SEGMI_LAUNCH_CHECK("conv3d_wgrad(reduce)");
   if (db) {
-    float* bws = (float*)((char*)workspace + align256((int64_t)slabs * nout * 4));
+    float* bws = (float*)((char*)gsum + align256((int64_t)kSlabGroups * nout * 4));
     return segmi_bias_grad(dtype, dy, db, bws, stream);
   }
   return SEGMI_OK;

@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 
   const char* xb = (const char*)p.x;
   const char* yb = (const char*)p.dy;
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  // Register-staged software pipeline: the global loads of tile t+1 are issued before the MFMA
+  // phase of tile t and land in LDS after it (global latency hides under compute).
+  constexpr int NLY = (G::NV * G::CPR + 255) / 256, NLX = (G::XROWS * G::CPR + 255) / 256;
+  frag_t ry[NLY], rx[NLX];
+  auto fetch = [&](int tile) {
     int t = tile;
     const int txi = t % p.tx; t /= p.tx;
     const int tyi = t % p.ty; t /= p.ty;
@@ -113,32 +117,51 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     const int n = t / p.tz;
     const int oz0 = tzi * TD, oy0 = tyi * TH, ox0 = txi * TW;
     const int iz0 = oz0 * S - G::PAD, iy0 = oy0 * S - G::PAD, ix0 = ox0 * S - G::PAD;
-    __syncthreads();
-    // stage dY tile [NV][16*CT]
-    for (int i = tid; i < G::NV * G::CPR; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NLY; ++k) {        // dY tile [NV][16*CT]
+      const int i = tid + 256 * k;
       const int v = i / G::CPR, ch = i % G::CPR;
       const int z = oz0 + v / (TW * TH), y = oy0 + (v / TW) % TH, x = ox0 + v % TW;
-      frag_t val = frag_t{0u, 0u, 0u, 0u};
-      if (z < p.Dy && y < p.Hy && x < p.Wy) {
+      ry[k] = frag_t{0u, 0u, 0u, 0u};
+      if (i < G::NV * G::CPR && z < p.Dy && y < p.Hy && x < p.Wy) {
         const int64_t e = ((((int64_t)n * p.Dy + z) * p.Hy + y) * p.Wy + x) * p.ldy + co0;
-        val = *reinterpret_cast<const frag_t*>(yb + e * (int64_t)sizeof(T) + ch * 16);
+        ry[k] = *reinterpret_cast<const frag_t*>(yb + e * (int64_t)sizeof(T) + ch * 16);
       }
-      *reinterpret_cast<frag_t*>(ysm + v * G::ROWB + ch * 16) = val;
     }
-    // stage X halo tile [HD*HH*HW][16*CT]
-    for (int i = tid; i < G::XROWS * G::CPR; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {        // X halo tile [HD*HH*HW][16*CT]
+      const int i = tid + 256 * k;
       const int v = i / G::CPR, ch = i % G::CPR;
       const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
       const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
-      frag_t val = frag_t{0u, 0u, 0u, 0u};
-      if ((unsigned)z < (unsigned)p.Dx && (unsigned)y < (unsigned)p.Hx &&
+      rx[k] = frag_t{0u, 0u, 0u, 0u};
+      if (i < G::XROWS * G::CPR && (unsigned)z < (unsigned)p.Dx && (unsigned)y < (unsigned)p.Hx &&
           (unsigned)x < (unsigned)p.Wx) {
         const int64_t e = ((((int64_t)n * p.Dx + z) * p.Hx + y) * p.Wx + x) * p.ldx + ci0;
-        val = *reinterpret_cast<const frag_t*>(xb + e * (int64_t)sizeof(T) + ch * 16);
+        rx[k] = *reinterpret_cast<const frag_t*>(xb + e * (int64_t)sizeof(T) + ch * 16);
       }
-      *reinterpret_cast<frag_t*>(xsm + v * G::ROWB + ch * 16) = val;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLY; ++k) {
+      const int i = tid + 256 * k;
+      if (i < G::NV * G::CPR)
+        *reinterpret_cast<frag_t*>(ysm + (i / G::CPR) * G::ROWB + (i % G::CPR) * 16) = ry[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {
+      const int i = tid + 256 * k;
+      if (i < G::XROWS * G::CPR)
+        *reinterpret_cast<frag_t*>(xsm + (i / G::CPR) * G::ROWB + (i % G::CPR) * 16) = rx[k];
+    }
+  };
+  if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();   // every wave is done reading the previous tile
+    commit();
     __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
 
 #pragma unroll
     for (int lg = 0; lg < G::NL / G::LPG; ++lg) {
@@ -253,7 +276,7 @@ static inline int wgrad_ct(int dtype, int cin, int cout) {
 static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int stride) {
   const int ct = wgrad_ct(dtype, x->c, dy->c);
   const int chunks = (x->c / (16 * ct)) * (dy->c / (16 * ct));
-  int gx = 512 / chunks;
+  int gx = 1024 / chunks;   // ~4 workgroups per CU: one stages while others compute
   if (gx < 1) gx = 1;
   const int nt = wgrad_tiles(dy, stride);
   return gx < nt ? gx : nt;
