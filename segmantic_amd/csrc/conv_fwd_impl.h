@@ -81,7 +81,31 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
   // fits in <= 64 VGPRs it is fetched BEFORE the halo staging so its latency hides under the
   // staging loads; otherwise the next k-step's fragments are prefetched one step ahead.
   constexpr bool PRE = G::NSTEP * NT <= 16;
+  // Multi-chunk layers (Cin > CK): the halo tile of chunk c+1 is fetched into registers before
+  // the MFMA phase of chunk c (register-staged pipeline) when the register budget allows.
+  constexpr int NCH = G::HD * G::HH * G::HW * G::CPR;
+  constexpr int NLD = (NCH + 255) / 256;
+  constexpr bool PF = (G::VTW * NT * 4 + NLD * 4) <= 160;
   const char* inb = (const char*)p.in;
+  frag_t stg[PF ? NLD : 1];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 256 * k;
+      const int v = i / G::CPR, ch = i % G::CPR;
+      const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
+      const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
+      frag_t val = frag_t{0u, 0u, 0u, 0u};
+      if (i < NCH && (unsigned)z < (unsigned)p.Di && (unsigned)y < (unsigned)p.Hi &&
+          (unsigned)x < (unsigned)p.Wi) {
+        const int64_t e = ((((int64_t)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi + c * CK;
+        val = *reinterpret_cast<const frag_t*>(inb + e * (int64_t)sizeof(T) + ch * 16);
+      }
+      if constexpr (PF) stg[k] = val;
+      else if (i < NCH) *reinterpret_cast<frag_t*>(smem + v * G::ROWB + ch * 16) = val;
+    }
+  };
+  if constexpr (PF) fetch(0);
   for (int c = 0; c < p.nchunks; ++c) {
     if (c > 0) __syncthreads();
     const char* wb = (const char*)p.wfrag +
@@ -94,20 +118,20 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
         for (int j = 0; j < NT; ++j)
           wall[s][j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
     }
-    // ---- stage the halo tile of chunk c
-    for (int i = tid; i < G::HD * G::HH * G::HW * G::CPR; i += 256) {
-      const int v = i / G::CPR, ch = i % G::CPR;
-      const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
-      const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
-      frag_t val = frag_t{0u, 0u, 0u, 0u};
-      if ((unsigned)z < (unsigned)p.Di && (unsigned)y < (unsigned)p.Hi &&
-          (unsigned)x < (unsigned)p.Wi) {
-        const int64_t e = ((((int64_t)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi + c * CK;
-        val = *reinterpret_cast<const frag_t*>(inb + e * (int64_t)sizeof(T) + ch * 16);
+    // ---- halo tile of chunk c -> LDS
+    if constexpr (PF) {
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        if (i < NCH) *reinterpret_cast<frag_t*>(smem + (i / G::CPR) * G::ROWB + (i % G::CPR) * 16) = stg[k];
       }
-      *reinterpret_cast<frag_t*>(smem + v * G::ROWB + ch * 16) = val;
+    } else {
+      fetch(c);
     }
     __syncthreads();
+    if constexpr (PF) {
+      if (c + 1 < p.nchunks) fetch(c + 1);
+    }
     frag_t wnext[NT];
     if constexpr (!PRE) {
 #pragma unroll
@@ -257,8 +281,15 @@ static int launch_conv_tiles(const ConvParams& p, hipStream_t st) {
 template <typename T, int CK, int KS, int S>
 static int launch_conv_nt(const ConvParams& p, hipStream_t st) {
   const int nt = p.Cout / 16;
-  if (nt % 4 == 0) return launch_conv_tiles<T, CK, KS, S, 4>(p, st);
-  if (nt % 2 == 0) return launch_conv_tiles<T, CK, KS, S, 2>(p, st);
+  // output-channel tiles per workgroup: as many as divide Cout (input tile reuse), but fewer
+  // when the launch would not fill the chip (deep levels: 8^3 .. 16^3 voxels)
+  const bool wide = p.Wo > 8;
+  const int td = S == 1 ? 4 : 2, th = S == 1 ? (wide ? 8 : 4) : 4, tw = wide ? 16 : 8;
+  const int64_t tiles = (int64_t)p.N * cdiv(p.Do, td) * cdiv(p.Ho, th) * cdiv(p.Wo, tw);
+  int sel = nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);
+  while (sel > 1 && tiles * (nt / sel) < 512) sel /= 2;
+  if (sel == 4) return launch_conv_tiles<T, CK, KS, S, 4>(p, st);
+  if (sel == 2) return launch_conv_tiles<T, CK, KS, S, 2>(p, st);
   return launch_conv_tiles<T, CK, KS, S, 1>(p, st);
 }
 
