@@ -16,7 +16,8 @@ int bn_stats_rows_for(const segmi_act* x);
 int stats_reserve_rows();
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
-                   const float* bias, int stride, hipStream_t st);
+                   const float* bias, const float* alpha, const segmi_act* res, int stride,
+                   hipStream_t st);
 
 struct DirectParams {
   const void* in;
@@ -180,9 +181,12 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
   }
   SEGMI_CHECK_ARG(w_src, "conv3d: direct path (channels not multiples of 16) needs w_src");
   SEGMI_CHECK_ARG(w_kind == 0 || w_kind == 1, "conv3d: bad w_kind %d", w_kind);
-  if (conv_small_ok(in->c, out->c, ksize) && w_kind == 0 && !prelu_alpha && !residual &&
-      out->ld % 4 == 0 && ((uintptr_t)out->data % (4 * es)) == 0) {
-    const int rc = conv_small_fwd(dtype, in, out, w_src, bias, stride, st);
+  if (conv_small_ok(in->c, out->c, ksize) && w_kind == 0 && out->ld % 4 == 0 &&
+      ((uintptr_t)out->data % (4 * es)) == 0 &&
+      (!residual || (residual->ld % 4 == 0 && ((uintptr_t)residual->data % (4 * es)) == 0))) {
+    SEGMI_CHECK_ARG(!stats_partials || (!prelu_alpha && !residual),
+                    "conv3d: fused statistics are taken before PReLU/residual");
+    const int rc = conv_small_fwd(dtype, in, out, w_src, bias, prelu_alpha, residual, stride, st);
     if (rc) return rc;
     if (stats_partials) return bn_stats_launch(dtype, out, stats_partials, st);
     return SEGMI_OK;

@@ -14,7 +14,9 @@ struct SmallConvParams {
   void* out;
   const float* w;     // torch layout [COUT][Cin][27]
   const float* bias;
-  int N, Di, Hi, Wi, Do, Ho, Wo, Cin, ldi, ldo, stride;
+  const float* alpha;  // PReLU slope (nullable)
+  const void* res;     // residual view (nullable), added after the activation
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cin, ldi, ldo, ldr, stride;
 };
 
 template <typename T, int COUT>
@@ -59,9 +61,19 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
         }
       }
     }
-    T* op = out + v * p.ldo;
+    if (p.alpha) {
+      const float al = *p.alpha;
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4) store4<T>(op + c, f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+      for (int c = 0; c < COUT; ++c) acc[c] = acc[c] > 0.f ? acc[c] : al * acc[c];
+    }
+    T* op = out + v * p.ldo;
+    const T* rp = p.res ? (const T*)p.res + v * p.ldr : nullptr;
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) {
+      f32x4 o = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+      if (rp) o += load4<T>(rp + c);
+      store4<T>(op + c, o);
+    }
   }
 }
 
@@ -160,9 +172,11 @@ bool conv_small_ok(int cin, int cout, int ksize) {
 }
 
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
-                   const float* bias, int stride, hipStream_t st) {
+                   const float* bias, const float* alpha, const segmi_act* res, int stride,
+                   hipStream_t st) {
   SmallConvParams p{};
-  p.in = in->data; p.out = out->data; p.w = w; p.bias = bias;
+  p.in = in->data; p.out = out->data; p.w = w; p.bias = bias; p.alpha = alpha;
+  p.res = res ? res->data : nullptr; p.ldr = res ? res->ld : 0;
   p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
   p.Cin = in->c; p.ldi = in->ld; p.ldo = out->ld; p.stride = stride;
   const int64_t total = act_voxels(out);

@@ -48,14 +48,20 @@ __device__ __forceinline__ void load_logits(const T* p, int k, float (&v)[KMAX])
   }
 }
 
-template <int KMAX>
+// FAST: hardware exp2 (v_exp_f32, ~1 ulp in exp2 but ~2e-7 relative after the log2(e) scaling)
+// for the bf16 path, where the logits carry 8 bits anyway; the f32 parity path keeps the
+// correctly-rounded libm expf.
+template <int KMAX, bool FAST>
 __device__ __forceinline__ void softmax_inplace(int k, float (&v)[KMAX]) {
   float m = -INFINITY;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) if (j < k) m = fmaxf(m, v[j]);
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) if (j < k) { v[j] = expf(v[j] - m); s += v[j]; }
+  for (int j = 0; j < KMAX; ++j) if (j < k) {
+    v[j] = FAST ? __builtin_amdgcn_exp2f((v[j] - m) * 1.4426950408889634f) : expf(v[j] - m);
+    s += v[j];
+  }
   const float inv = 1.f / s;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) if (j < k) v[j] *= inv;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float x[KMAX];
     load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
-    softmax_inplace<KMAX>(p.k, x);
+    softmax_inplace<KMAX, sizeof(T) == 2>(p.k, x);
     const int lab = (int)lb[v];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float x[KMAX];
     load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
-    softmax_inplace<KMAX>(p.k, x);
+    softmax_inplace<KMAX, sizeof(T) == 2>(p.k, x);
     const int lab = (int)lb[v];
     float dot = 0.f;
     float dp[KMAX];

@@ -68,6 +68,91 @@ __global__ void sw_scatter_kernel(const T* __restrict__ pred, WinList wl, const 
   }
 }
 
+// 4-channel vector variant of sw_scatter_kernel (K % 4 == 0, 16-byte aligned rows): one thread
+// per (voxel, 4 channels): f32x4 read-modify-write of the accumulator, 8/16-byte prediction loads
+template <typename T>
+__global__ void sw_scatter4_kernel(const T* __restrict__ pred, WinList wl, const float* __restrict__ imp,
+                                   float* __restrict__ acc, float* __restrict__ cnt, int D, int H,
+                                   int W, int K, int lda, int rd, int rh, int rw, int ldp, int bz0,
+                                   int by0, int bx0, int bd, int bh, int bw) {
+  const int kg = K / 4;
+  const int64_t total = (int64_t)bd * bh * bw * kg;
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int k = (int)(e % kg) * 4;
+    int64_t t = e / kg;
+    const int x = bx0 + (int)(t % bw); t /= bw;
+    const int y = by0 + (int)(t % bh); t /= bh;
+    const int z = bz0 + (int)t;
+    const int64_t vox = ((int64_t)z * H + y) * W + x;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    float c = 0.f;
+    bool touched = false;
+    for (int w = 0; w < wl.n; ++w) {
+      const int lz = z - wl.z[w], ly = y - wl.y[w], lx = x - wl.x[w];
+      if ((unsigned)lz < (unsigned)rd && (unsigned)ly < (unsigned)rh && (unsigned)lx < (unsigned)rw) {
+        const int64_t lv = ((int64_t)lz * rh + ly) * rw + lx;
+        const float wt = imp ? imp[lv] : 1.f;
+        const f32x4 pv = load4<T>(pred + (((int64_t)w * rd * rh * rw) + lv) * ldp + k);
+        if (!touched) {   // first contributing window: fetch the running sums (same add order
+          a = *reinterpret_cast<const f32x4*>(acc + vox * lda + k);   // as the scalar kernel)
+          c = (cnt && k == 0) ? cnt[vox] : 0.f;
+          touched = true;
+        }
+        a += wt * pv;
+        c += wt;
+      }
+    }
+    if (touched) {
+      *reinterpret_cast<f32x4*>(acc + vox * lda + k) = a;
+      if (cnt && k == 0) cnt[vox] = c;
+    }
+  }
+}
+
+// argmax with K/4 lanes per voxel (K in {4,8,16,32,64,128,256}): 16-byte loads, lane-group
+// butterfly keeping torch.argmax semantics (first maximal index; first NaN wins)
+__device__ __forceinline__ bool am_better(float av, int ai, float bv, int bi) {
+  // true when (bv, bi) should replace (av, ai)
+  const bool an = av != av, bn = bv != bv;
+  if (an || bn) return bn && (!an || bi < ai);
+  return bv > av || (bv == av && bi < ai);
+}
+template <typename T, typename L>
+__global__ void argmax4_kernel(const T* __restrict__ lg, const float* __restrict__ cnt,
+                               float* __restrict__ wb, L* __restrict__ labels, int64_t nvox, int K,
+                               int ld) {
+  const int tpv = K / 4;                       // lanes per voxel (power of two <= 64)
+  const int64_t total = nvox * tpv;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e0 = blockIdx.x * 256ll; e0 < total; e0 += stride) {   // whole wave iterates together
+    const int64_t e = e0 + threadIdx.x;
+    const bool live = e < total;
+    const int64_t v = live ? e / tpv : 0;
+    const int k = (int)(e % tpv) * 4;
+    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      x = load4<T>(lg + v * ld + k);
+      if (cnt) {
+        const float c = cnt[v];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = x[j] / c;
+      }
+      if (wb) *reinterpret_cast<f32x4*>(wb + v * ld + k) = x;
+    }
+    float bv = x[0];
+    int bi = k;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (am_better(bv, bi, x[j], k + j)) { bv = x[j]; bi = k + j; }
+    for (int o = 1; o < tpv; o <<= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (am_better(bv, bi, ov, oi)) { bv = ov; bi = oi; }
+    }
+    if (live && k == 0) labels[v] = (L)bi;
+  }
+}
+
 template <typename T, typename L>
 __global__ void argmax_kernel(const T* __restrict__ lg, const float* __restrict__ cnt,
                               float* __restrict__ wb, L* __restrict__ labels, int64_t nvox, int K,
@@ -193,8 +278,19 @@ int segmi_sw_scatter_add(int dtype, const segmi_act* pred, const int32_t* starts
   z1 = z1 > acc->d ? acc->d : z1; y1 = y1 > acc->h ? acc->h : y1; x1 = x1 > acc->w ? acc->w : x1;
   if (z1 <= z0 || y1 <= y0 || x1 <= x0) return SEGMI_OK;
   const int bd = z1 - z0, bh = y1 - y0, bw = x1 - x0;
-  const int grid = grid_for((int64_t)bd * bh * bw * acc->c);
   hipStream_t st = (hipStream_t)stream;
+  const int es = dtype_size(dtype);
+  if (acc->c % 4 == 0 && acc->ld % 4 == 0 && pred->ld % 4 == 0 && ((uintptr_t)acc->data % 16) == 0 &&
+      ((uintptr_t)pred->data % (4 * es)) == 0) {
+    const int g4 = grid_for((int64_t)bd * bh * bw * (acc->c / 4));
+    if (dtype == SEGMI_F32)
+      hipLaunchKernelGGL(sw_scatter4_kernel<float>, g4, 256, 0, st, (const float*)pred->data, wl, importance, (float*)acc->data, cnt, acc->d, acc->h, acc->w, acc->c, acc->ld, pred->d, pred->h, pred->w, pred->ld, z0, y0, x0, bd, bh, bw);
+    else
+      hipLaunchKernelGGL(sw_scatter4_kernel<bf16_t>, g4, 256, 0, st, (const bf16_t*)pred->data, wl, importance, (float*)acc->data, cnt, acc->d, acc->h, acc->w, acc->c, acc->ld, pred->d, pred->h, pred->w, pred->ld, z0, y0, x0, bd, bh, bw);
+    SEGMI_LAUNCH_CHECK("sw_scatter_add");
+    return SEGMI_OK;
+  }
+  const int grid = grid_for((int64_t)bd * bh * bw * acc->c);
   if (dtype == SEGMI_F32)
     hipLaunchKernelGGL(sw_scatter_kernel<float>, grid, 256, 0, st, (const float*)pred->data, wl, importance, (float*)acc->data, cnt, acc->d, acc->h, acc->w, acc->c, acc->ld, pred->d, pred->h, pred->w, pred->ld, z0, y0, x0, bd, bh, bw);
   else
@@ -206,8 +302,29 @@ int segmi_sw_scatter_add(int dtype, const segmi_act* pred, const int32_t* starts
 static int argmax_launch(int dtype, const segmi_act* lg, const float* cnt, int write_back,
                          void* labels, int label_bytes, hipStream_t st) {
   const int64_t nvox = act_voxels(lg);
-  const int grid = grid_for(nvox);
   float* wb = write_back ? (float*)lg->data : nullptr;
+  const int es = dtype_size(dtype);
+  const int tpv = lg->c / 4;
+  if (lg->c % 4 == 0 && tpv >= 1 && tpv <= 64 && (tpv & (tpv - 1)) == 0 && lg->ld % 4 == 0 &&
+      ((uintptr_t)lg->data % (4 * es)) == 0) {
+    const int g4 = grid_for(nvox * tpv);
+#define ARGMAX4(T, L)                                                                      \
+  hipLaunchKernelGGL((argmax4_kernel<T, L>), g4, 256, 0, st, (const T*)lg->data, cnt, wb, \
+                     (L*)labels, nvox, lg->c, lg->ld)
+    if (dtype == SEGMI_F32) {
+      if (label_bytes == 1) ARGMAX4(float, uint8_t);
+      else if (label_bytes == 2) ARGMAX4(float, int16_t);
+      else ARGMAX4(float, int32_t);
+    } else {
+      if (label_bytes == 1) ARGMAX4(bf16_t, uint8_t);
+      else if (label_bytes == 2) ARGMAX4(bf16_t, int16_t);
+      else ARGMAX4(bf16_t, int32_t);
+    }
+#undef ARGMAX4
+    SEGMI_LAUNCH_CHECK("argmax");
+    return SEGMI_OK;
+  }
+  const int grid = grid_for(nvox);
 #define ARGMAX(T, L)                                                                     \
   hipLaunchKernelGGL((argmax_kernel<T, L>), grid, 256, 0, st, (const T*)lg->data, cnt, wb, \
                      (L*)labels, nvox, lg->c, lg->ld)

@@ -339,15 +339,18 @@ def test_adam_sgd_match_torch():
 
 def test_argmax_bit_exact_with_ties():
     g = torch.Generator().manual_seed(81)
-    lg = torch.randint(-3, 4, (2, 7, 5, 6, 9), generator=g).float()  # many exact ties
-    ref = torch.argmax(lg, dim=1)
-    for dt in (torch.float32, torch.bfloat16):
-        ld = to_ndhwc(lg, dt)
-        for ldt in (torch.uint8, torch.int16, torch.int32):
-            lab = torch.empty((2, 5, 6, 9), dtype=ldt, device=DEV)
-            ops.argmax(ld, lab)
-            torch.cuda.synchronize()
-            assert torch.equal(lab.cpu().long(), ref)
+    for K in (7, 4, 16, 32):     # scalar kernel (7) and the K/4-lanes-per-voxel kernel
+        lg = torch.randint(-3, 4, (2, K, 5, 6, 9), generator=g).float()  # many exact ties
+        lg[0, K // 2, 1, 2, 3] = float("nan")                             # NaN counts as maximal
+        lg[1, 1, 0, 0, 0] = float("nan"); lg[1, K - 1, 0, 0, 0] = float("nan")   # first NaN wins
+        ref = torch.argmax(lg, dim=1)
+        for dt in (torch.float32, torch.bfloat16):
+            ld = to_ndhwc(lg, dt)
+            for ldt in (torch.uint8, torch.int16, torch.int32):
+                lab = torch.empty((2, 5, 6, 9), dtype=ldt, device=DEV)
+                ops.argmax(ld, lab)
+                torch.cuda.synchronize()
+                assert torch.equal(lab.cpu().long(), ref), (K, dt, ldt)
 
 
 def test_sliding_window_ops_match_oracle():
