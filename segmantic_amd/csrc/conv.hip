@@ -211,9 +211,8 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
 }
 
 int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out) {
-  (void)dtype;
   if (!in || !out) return 0;
-  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(in) + stats_reserve_rows();
+  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(dtype, in) + stats_reserve_rows();
   return bn_stats_rows_for(out) + stats_reserve_rows();
 }
 

@@ -115,7 +115,11 @@ __device__ __forceinline__ void convt_wave_compute(f32x4 (&acc)[3][4][NT], const
   }
 }
 
-template <typename T, int NT, int TD, int TH, int TW, int W>
+// Epilogue of one wave: bias, BN statistics, PReLU, residual, NDHWC store.
+// FAST (tile completely inside the output): no per-lane bounds checks, 32-bit per-lane offsets
+// relative to a wave-uniform tile base -- the slow form spends ~45 VALU ops per 16x16 tile on
+// 64-bit index arithmetic, more than the MFMA work of this kernel.
+template <typename T, int NT, int TD, int TH, int TW, int W, bool FAST>
 __device__ __forceinline__ void convt_wave_store(const f32x4 (&acc)[3][4][NT],
                                                  const ConvTParams& p, int n, int iz0, int iy0,
                                                  int ix0, int nt0, int g, int r,
@@ -130,18 +134,31 @@ __device__ __forceinline__ void convt_wave_store(const f32x4 (&acc)[3][4][NT],
   const float alpha = has_alpha ? *p.alpha : 0.f;
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.res;
+  // wave-uniform base of the tile's first output voxel, per-lane 32-bit offsets for the 4 tiles
+  const int64_t tile_vox = (((int64_t)n * p.Do + 2 * iz0) * p.Ho + 2 * iy0) * p.Wo + 2 * ix0;
+  int lvox[4];
+#pragma unroll
+  for (int vt = 0; vt < 4; ++vt) {
+    const int idx = vt * 16 + r;
+    lvox[vt] = (2 * (idx / (TW * TH)) * p.Ho + 2 * ((idx / TW) % TH)) * p.Wo + 2 * (idx % TW);
+  }
 #pragma unroll
   for (int ci = 0; ci < kCtNCls[W]; ++ci) {
     const int cls = kCtCls[W][ci];
     const int rw = cls & 1, rh = (cls >> 1) & 1, rd = (cls >> 2) & 1;
+    const int cls_vox = (rd * p.Ho + rh) * p.Wo + rw;
+    T* ob = outp + (tile_vox + cls_vox) * p.ldo + nt0 * 16 + 4 * g;
+    const T* rb = resp ? resp + (tile_vox + cls_vox) * p.ldr + nt0 * 16 + 4 * g : nullptr;
 #pragma unroll
     for (int vt = 0; vt < 4; ++vt) {
-      const int idx = vt * 16 + r;
-      const int oz = 2 * (iz0 + idx / (TW * TH)) + rd;
-      const int oy = 2 * (iy0 + (idx / TW) % TH) + rh;
-      const int ox = 2 * (ix0 + idx % TW) + rw;
-      const bool valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
-      const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+      bool valid = true;
+      if constexpr (!FAST) {
+        const int idx = vt * 16 + r;
+        const int oz = 2 * (iz0 + idx / (TW * TH)) + rd;
+        const int oy = 2 * (iy0 + (idx / TW) % TH) + rh;
+        const int ox = 2 * (ix0 + idx % TW) + rw;
+        valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4 v = acc[ci][vt][j] + bias4[j];
@@ -154,9 +171,8 @@ __device__ __forceinline__ void convt_wave_store(const f32x4 (&acc)[3][4][NT],
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
           }
-          const int co = (nt0 + j) * 16 + 4 * g;
-          if (resp) v += load4<T>(resp + vox * p.ldr + co);
-          store4<T>(outp + vox * p.ldo + co, v);
+          if (rb) v += load4<T>(rb + (int64_t)lvox[vt] * p.ldr + j * 16);
+          store4<T>(ob + (int64_t)lvox[vt] * p.ldo + j * 16, v);
         }
       }
     }
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
 
   f32x4 acc[3][4][NT];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < kCtNCls[0] + 2; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -195,7 +211,25 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
     vaddr[vt] = ((z * G::HH + y) * G::HW + x) * G::ROWB;
   }
 
-  const char* inb = (const char*)p.in;
+  // staging descriptors: 32-bit offsets relative to the wave-uniform tile base; interior tiles
+  // (halo inside the image) load without per-lane bounds checks
+  constexpr int NCH = G::HD * G::HH * G::HW * G::CPR;
+  constexpr int NLD = (NCH + 255) / 256;
+  const char* tile_in = (const char*)p.in +
+      ((((int64_t)n * p.Di + iz0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * (int64_t)sizeof(T);
+  const bool interior = iz0 + TD < p.Di && iy0 + TH < p.Hi && ix0 + TW < p.Wi;
+  int s_goff[NLD], s_loff[NLD];
+  bool s_ok[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + 256 * k;
+    const int v = i / G::CPR, ch = i % G::CPR;
+    const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
+    s_loff[k] = v * G::ROWB + ch * 16;
+    s_goff[k] = ((hz * p.Hi + hy) * p.Wi + hx) * p.ldi * (int)sizeof(T) + ch * 16;
+    s_ok[k] = i < NCH && (interior || (iz0 + hz < p.Di && iy0 + hy < p.Hi && ix0 + hx < p.Wi));
+  }
+
   const char* wfrag = (const char*)p.wfrag;
   for (int c = 0; c < p.nchunks; ++c) {
     if (c > 0) __syncthreads();
@@ -204,16 +238,12 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
     else if (wave == 1) convt_wave_loadw<T, CK, NT, TD, TH, TW, 1>(wall, wfrag, p, c, nt0, lane);
     else if (wave == 2) convt_wave_loadw<T, CK, NT, TD, TH, TW, 2>(wall, wfrag, p, c, nt0, lane);
     else convt_wave_loadw<T, CK, NT, TD, TH, TW, 3>(wall, wfrag, p, c, nt0, lane);
-    for (int i = tid; i < G::HD * G::HH * G::HW * G::CPR; i += 256) {
-      const int v = i / G::CPR, ch = i % G::CPR;
-      const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
-      const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
+    const char* cin = tile_in + c * CK * (int)sizeof(T);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
       frag_t val = frag_t{0u, 0u, 0u, 0u};
-      if (z < p.Di && y < p.Hi && x < p.Wi) {
-        const int64_t e = ((((int64_t)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi + c * CK;
-        val = *reinterpret_cast<const frag_t*>(inb + e * (int64_t)sizeof(T) + ch * 16);
-      }
-      *reinterpret_cast<frag_t*>(smem + v * G::ROWB + ch * 16) = val;
+      if (s_ok[k]) val = *reinterpret_cast<const frag_t*>(cin + s_goff[k]);
+      if (tid + 256 * k < NCH) *reinterpret_cast<frag_t*>(smem + s_loff[k]) = val;
     }
     __syncthreads();
     if (wave == 0) convt_wave_compute<T, CK, NT, TD, TH, TW, 0>(acc, smem, vaddr, wall, g);
@@ -228,10 +258,16 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
     ssum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (wave == 0) convt_wave_store<T, NT, TD, TH, TW, 0>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
-  else if (wave == 1) convt_wave_store<T, NT, TD, TH, TW, 1>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
-  else if (wave == 2) convt_wave_store<T, NT, TD, TH, TW, 2>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
-  else convt_wave_store<T, NT, TD, TH, TW, 3>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq);
+  const bool full = 2 * (iz0 + TD) <= p.Do && 2 * (iy0 + TH) <= p.Ho && 2 * (ix0 + TW) <= p.Wo;
+#define CT_STORE(WV, F) convt_wave_store<T, NT, TD, TH, TW, WV, F>(acc, p, n, iz0, iy0, ix0, nt0, g, r, ssum, ssq)
+  if (full) {
+    if (wave == 0) CT_STORE(0, true); else if (wave == 1) CT_STORE(1, true);
+    else if (wave == 2) CT_STORE(2, true); else CT_STORE(3, true);
+  } else {
+    if (wave == 0) CT_STORE(0, false); else if (wave == 1) CT_STORE(1, false);
+    else if (wave == 2) CT_STORE(2, false); else CT_STORE(3, false);
+  }
+#undef CT_STORE
 
   if (p.stats) {
     __syncthreads();
@@ -301,9 +337,10 @@ static int launch_convt_mfma_t(ConvTParams p, hipStream_t st) {
   return launch_convt_nt<T, 16>(p, st);
 }
 
-static inline int convt_mfma_rows(const segmi_act* in) {
+static inline int convt_mfma_rows(int dtype, const segmi_act* in) {
   const bool wide = in->w > 8;
   const int td = 2, th = wide ? 2 : 4, tw = wide ? 16 : 8;
+  (void)dtype;
   return in->n * cdiv(in->d, td) * cdiv(in->h, th) * cdiv(in->w, tw);
 }
 
