@@ -219,15 +219,26 @@ def main():
                 ach = flops / (avg * 1e-3) / 1e12
                 peak = MFMA_PEAK_BF16_TFLOPS if args.precision == "bf16" else MFMA_PEAK_F32_TFLOPS
                 es = 2 if args.precision == "bf16" else 4
+                # Algorithmic bytes per voxel of this launch: 16 channels in + 16 residual + 16 out
+                # (DESIGN.md section 4).  Intensity 864*16/(48*es) = 144 FLOP/B (bf16) is below
+                # the chip ridge (~310 FLOP/B): HBM is the roof that bounds this kernel.
+                abytes = kern_units * 16 * es * 3
+                gbps = abytes / (avg * 1e-3) / 1e9
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+                if (os.path.exists(tpath) and args.precision == "bf16" and args.batch == 8
+                        and args.size == 128 and K == 16):
+                    # PMC counters cannot be read from inside the process: measured offline with
+                    # rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)
+                    traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
                 out["roofline"] = {
-                    "kernel": "conv_fwd_mfma_kernel (full-resolution 16->16 k3 conv + residual epilogue)",
-                    "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": None,
+                    "kernel": "conv_ring_mfma_kernel (full-resolution 16->16 k3 conv + residual epilogue)",
+                    "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
+                    "frac": gbps / 8000.0, "traffic": traffic,
                     "avg_launch_ms": avg, "launches": len(ms),
-                    "algorithmic_flops_per_launch": flops,
-                    "hbm_view": {"algorithmic_bytes_per_launch": kern_units * 16 * es * 3,
-                                 "achieved_GBps": kern_units * 16 * es * 3 / (avg * 1e-3) / 1e9,
-                                 "peak_GBps": 8000.0},
+                    "algorithmic_bytes_per_launch": abytes,
+                    "mfma_view": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
+                                  "peak_TFLOPs": peak, "frac": ach / peak},
                 }
             step_flops = args.batch * args.size ** 3 * FLOP_PER_VOXEL_TRAIN_K16 if K == 16 else None
             if step_flops:
