@@ -127,6 +127,14 @@ class UNetParams(nn.Module):
                                        list(self.strides), True))
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 # =============================================================================================
 # execution engine
 # =============================================================================================
@@ -403,18 +411,29 @@ class UNetEngine:
         input gradient whose per-channel sum is identically zero (sum_v dr = gamma*invstd*(S -
         N*S/N - (T/N)*sum xhat) = 0), so db == 0 exactly; the arena entry stays at its initial
         zero instead of spending a pass over dy to compute rounding noise."""
-        if conv.transposed:
-            # dW_T[ci][co][tap]: stride-2 conv wgrad with x := dy (fine grid), dy := x (coarse)
-            nbytes = ops.conv3d_wgrad_workspace(dy, x, 3, 2)
-            ws = self._scratch_buf("wgrad", nbytes)
-            self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, dy, x, conv.gw, None, 3, 2, ws)
-            if need_bias:
-                ops.bias_grad(dy, conv.gb, ws)
-        else:
-            nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
-            ws = self._scratch_buf("wgrad", nbytes)
-            self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw,
-                        conv.gb if need_bias else None, conv.k, conv.stride, ws)
+        # Weight gradients have no consumer until the optimiser: they run on a side HIP stream,
+        # concurrently with the dgrad / BatchNorm-backward chain of the main stream (the
+        # mid / deep levels do not fill 256 CUs with one kernel at a time).  All wgrads share the
+        # side stream, hence also their scratch buffer, in issue order.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else None
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            if conv.transposed:
+                # dW_T[ci][co][tap]: stride-2 conv wgrad with x := dy (fine), dy := x (coarse)
+                nbytes = ops.conv3d_wgrad_workspace(dy, x, 3, 2)
+                ws = self._scratch_buf("wgrad", nbytes)
+                self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, dy, x, conv.gw, None, 3, 2, ws)
+                if need_bias:
+                    ops.bias_grad(dy, conv.gb, ws)
+            else:
+                nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
+                ws = self._scratch_buf("wgrad", nbytes)
+                self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw,
+                            conv.gb if need_bias else None, conv.k, conv.stride, ws)
 
     def _dgrad(self, conv: _Conv, dy, dx, residual=None):
         """dx = dgrad(conv, dy) (+ residual)."""
@@ -630,6 +649,7 @@ class UNetEngine:
         if not self._saved:
             raise RuntimeError("backward() needs a preceding training-mode forward()")
         self._level_bwd(self.levels, dlogits)
+        self._join_side()
 
     # ------------------------------------------------------------------ live kernel timing
     # bench.py sets `timed = {"<conv prefix>:<fwd|wgrad|dgrad>"}`; the matching C-ABI call is
@@ -650,9 +670,22 @@ class UNetEngine:
         return [s.elapsed_time(e) for s, e in self.timings.get(key, [])]
 
     grad_hook = None  # callable(lo_offset): gradients at arena offsets >= lo are final
+    overlap_wgrad = True
+    _side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _join_side(self):
+        """main stream waits for every weight-gradient kernel issued so far"""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def _grads_ready(self, lo: int):
         if self.grad_hook is not None:
+            self._join_side()     # the hook (bucketed all-reduce) orders itself after the main stream
             self.grad_hook(lo)
 
     def bump(self):
