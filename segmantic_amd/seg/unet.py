@@ -462,10 +462,14 @@ class UNetEngine:
         cur = x
         nun = len(ru["units"])
         saved = {"x": x}
-        # residual branch first, straight into `out` (then read back as the epilogue residual)
+        # residual branch straight into `out` (read back as the epilogue residual of the last
+        # unit); it is independent of the conv-unit chain, so it runs on a side stream
+        br = None
         if ru["res"] is not None:
             rc = ru["res"]
-            ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
+            br = self._fork_branch()
+            with torch.cuda.stream(br) if br is not None else _NullCtx():
+                ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
             resid = out
         else:
             resid = x
@@ -473,6 +477,7 @@ class UNetEngine:
             last = i == nun - 1
             if bn is None:
                 # conv-only last unit (top of the net): out = conv(cur) + residual
+                self._join_branch(br)
                 self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, cur, out, conv.fwd_pack(), conv.w,
                             0, conv.b, conv.k, conv.stride, residual=resid)
                 saved[f"in{i}"] = cur
@@ -482,6 +487,7 @@ class UNetEngine:
             saved[f"in{i}"] = cur
             saved[f"r{i}"] = r
             if last:
+                self._join_branch(br)
                 ops.bn_act_fwd(r, out, bn.scale, bn.shift, bn.alpha, residual=resid)
             else:
                 a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
@@ -496,6 +502,14 @@ class UNetEngine:
         sv = self._saved[pre]
         x = sv["x"]
         nun = len(ru["units"])
+        rc = ru["res"]
+        # the residual conv's input gradient depends only on dout: side stream, joined before
+        # the first unit's dgrad accumulates on top of it
+        br = None
+        if rc is not None and dx is not None:
+            br = self._fork_branch()
+            with torch.cuda.stream(br) if br is not None else _NullCtx():
+                self._dgrad(rc, dout, dx, residual=extra)
         g = dout            # gradient flowing back through the conv branch
         for i in range(nun - 1, -1, -1):
             conv, bn = ru["units"][i]
@@ -513,7 +527,6 @@ class UNetEngine:
                 g = da
             else:
                 first_dr = dr
-        rc = ru["res"]
         if rc is not None:
             self._wgrad(rc, x, dout)
         # every parameter gradient of this unit (and of everything after it in the arena) is final
@@ -522,7 +535,7 @@ class UNetEngine:
             return
         conv0 = ru["units"][0][0]
         if rc is not None:
-            self._dgrad(rc, dout, dx, residual=extra)
+            self._join_branch(br)
             self._dgrad(conv0, first_dr, dx, residual=dx)
         else:
             # identity residual: dx = dgrad(conv0) + dout (+ extra)
@@ -535,9 +548,12 @@ class UNetEngine:
     def _ru_fwd_eval(self, ru, x, out):
         pre = ru["prefix"]
         n, d, h, w = self._down_shape(x.shape, ru["stride"])
+        br = None
         if ru["res"] is not None:
             rc = ru["res"]
-            ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
+            br = self._fork_branch()
+            with torch.cuda.stream(br) if br is not None else _NullCtx():
+                ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
             resid = out
         else:
             resid = x
@@ -546,12 +562,15 @@ class UNetEngine:
         for i, (conv, bn) in enumerate(ru["units"]):
             last = i == nun - 1
             if bn is None:
+                self._join_branch(br)
                 ops.conv3d_fwd(cur, out, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
                                residual=resid)
                 break
             sc, sh = bn.eval_affine()
             pack, wsrc, bias = conv.folded(sc, sh)
             dst = out if last else self._buf(f"{pre}.ea{i}", (n, d, h, w, conv.cout))
+            if last:
+                self._join_branch(br)
             ops.conv3d_fwd(cur, dst, pack, wsrc, 0, bias, conv.k, conv.stride,
                            prelu_alpha=bn.alpha, residual=resid if last else None)
             cur = dst
@@ -677,6 +696,27 @@ class UNetEngine:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
+
+    # residual-branch overlap on a second side stream: measured neutral on MI355X (the branch
+    # convs are short and the join sits on the critical path), so it is off by default
+    overlap_branches = False
+    _side2 = None
+
+    def _fork_branch(self):
+        """second side stream, ordered after the main stream's current point (None = disabled)"""
+        if not self.overlap_branches:
+            return None
+        if self._side2 is None:
+            self._side2 = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side2.wait_event(ev)
+        return self._side2
+
+    @staticmethod
+    def _join_branch(s):
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
 
     def _join_side(self):
         """main stream waits for every weight-gradient kernel issued so far"""
