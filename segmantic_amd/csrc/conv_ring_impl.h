@@ -75,16 +75,18 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
   const int nsteps_z = total_steps - seg * seg_steps < seg_steps ? total_steps - seg * seg_steps
                                                                 : seg_steps;
 
-  // ---- weights: resident for the whole column
+  // ---- weights: when the whole set is <= 16 KiB it lives in LDS behind the ring for the whole
+  // column (one conflict-free lane-linear ds_read_b128 per k-step); otherwise fragments are
+  // prefetched from L2 one k-step ahead.
   constexpr bool PRE = G::NSTEP * NT <= 16;
   const char* wb = (const char*)p.wfrag + (int64_t)nt0 * 1024 + lane * 16;
-  frag_t wall[PRE ? G::NSTEP : 1][NT];
+  char* wsm = smem + G::LDS_BYTES;
   if constexpr (PRE) {
-#pragma unroll
-    for (int s = 0; s < G::NSTEP; ++s)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        wall[s][j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
+    for (int i = tid; i < G::NSTEP * NT * 64; i += 256) {
+      const int s = i / (NT * 64), j = (i / 64) % NT, l = i % 64;
+      *reinterpret_cast<frag_t*>(wsm + (s * NT + j) * 1024 + l * 16) = *reinterpret_cast<const frag_t*>(
+          (const char*)p.wfrag + (((int64_t)s * p.ntiles_total) + nt0 + j) * 1024 + l * 16);
+    }
   }
 
   // ---- per-thread staging descriptors (plane-relative): same (y, x, chunk) every step
@@ -178,8 +180,10 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) wnext[j] = *reinterpret_cast<const frag_t*>(wb + (int64_t)j * 1024);
     }
-#pragma unroll
-    for (int s = 0; s < G::NSTEP; ++s) {
+    // LDS operand pipeline: the 8 voxel-tile fragments of k-step s+1 are issued BEFORE the 8
+    // MFMAs of k-step s (8 x 16 cycles cover the ~128-cycle LDS latency); without this the
+    // compiler schedules each ds_read one MFMA ahead of its use and every MFMA pair stalls.
+    auto step_loff = [&](int s) {
       int loff;
       if constexpr (G::SPT == 2) {
         const int t0 = 2 * s, t1 = 2 * s + 1 < 27 ? 2 * s + 1 : 0;
@@ -190,26 +194,47 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
         const int tap = (4 * s) / G::SPT, sub0 = (4 * s) % G::SPT;
         loff = pofs[tap / 9] + (((tap / 3) % 3) * G::HW + tap % 3) * G::ROWB + (sub0 + g) * 16;
       }
-      loff += lane_addr;
-      frag_t wf[NT];
-      if constexpr (PRE) {
+      return loff + lane_addr;
+    };
+    // One-step-ahead operand pipeline: [8 fragment reads of k-step s+1] then [8 x NT MFMAs of
+    // k-step s]; the sched_barriers keep hipcc from sinking each read next to its consumer.
+    frag_t a_cur[8], a_nxt[8], wf[NT], wf_nxt[NT];
+    {
+      const int l0 = step_loff(0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = wall[s][j];
-      } else {
+      for (int i = 0; i < 8; ++i)
+        a_cur[i] = *reinterpret_cast<const frag_t*>(smem + l0 + i * G::HW * G::ROWB);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = wnext[j];
-        if (s + 1 < G::NSTEP) {
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (PRE) wf[j] = *reinterpret_cast<const frag_t*>(wsm + j * 1024 + lane * 16);
+        else wf[j] = wnext[j];
+      }
+    }
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            wnext[j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)(s + 1) * p.ntiles_total + j) * 1024);
+    for (int s = 0; s < G::NSTEP; ++s) {
+      if (s + 1 < G::NSTEP) {   // everything read here is consumed in the NEXT k-step
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (PRE)
+            wf_nxt[j] = *reinterpret_cast<const frag_t*>(wsm + ((s + 1) * NT + j) * 1024 + lane * 16);
+          else
+            wf_nxt[j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)(s + 1) * p.ntiles_total + j) * 1024);
         }
-      }
+        const int l1 = step_loff(s + 1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const frag_t a = *reinterpret_cast<const frag_t*>(smem + loff + i * G::HW * G::ROWB);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma16<T>(wf[j], a, acc[i][j]);
+        for (int i = 0; i < 8; ++i)
+          a_nxt[i] = *reinterpret_cast<const frag_t*>(smem + l1 + i * G::HW * G::ROWB);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma16<T>(wf[j], a_cur[i], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = wf_nxt[j];
     }
     // ---- write the prefetched planes into the free ring slots (zb+6 .. zb+9 mod R)
 #pragma unroll
@@ -299,13 +324,14 @@ static int launch_conv_ring_cfg(ConvParams p, hipStream_t st) {
   p.tx = cdiv(p.Wo, G::TW);
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
   auto kern = conv_ring_mfma_kernel<T, CK, NT>;
+  constexpr int lds = G::LDS_BYTES + (G::NSTEP * NT <= 16 ? G::NSTEP * NT * 1024 : 0);
   static bool attr_done = false;
-  if (!attr_done && G::LDS_BYTES > 64 * 1024) {
+  if (!attr_done && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, grid, 256, lds, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(ring)");
   return SEGMI_OK;
 }
