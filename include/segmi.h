@@ -57,6 +57,20 @@ int64_t segmi_wpack_bytes(int dtype, int kind, int cin_k, int cout_k, int ksize)
 int segmi_wpack(int dtype, int kind, const float* w_src, const float* scale, int cin_k,
                 int cout_k, int ksize, void* packed, void* stream);
 
+/* Batched form: one launch re-packs every convolution of a network after an optimiser step
+ * (the per-step equivalent of torch re-reading .weight in each Conv3d.forward/backward).
+ * `descs_host[ndesc]` is validated on the host on every call; when `upload` != 0 it is copied
+ * (stream-ordered) into `descs_dev` (device, ndesc * sizeof(segmi_wpack_desc) bytes) first,
+ * otherwise `descs_dev` must already hold the same table from an earlier call. */
+typedef struct segmi_wpack_desc {
+  const float* w_src;  /* device f32 source weight                                   */
+  const float* scale;  /* device f32[cout_k] or NULL                                 */
+  void* packed;        /* device destination, segmi_wpack_bytes(...) bytes            */
+  int32_t kind, cin_k, cout_k, ksize;
+} segmi_wpack_desc;
+int segmi_wpack_batch(int dtype, const segmi_wpack_desc* descs_host, int ndesc,
+                      segmi_wpack_desc* descs_dev, int upload, void* stream);
+
 /* ---------------------------------------------------------------- convolution ---------- */
 /* Conv3d k in {1,3}, stride in {1,2}, pad (k-1)/2, fused epilogue:
  *   v = conv(in) + bias ; stats += (v, v^2) ; v = prelu(v) ; v += residual ; out = v

@@ -23,6 +23,14 @@ class Act(C.Structure):
                 ("w", C.c_int32), ("c", C.c_int32), ("ld", C.c_int32)]
 
 
+class WpackDesc(C.Structure):
+    """``segmi_wpack_desc``: one entry of the batched weight-pack table."""
+
+    _fields_ = [("w_src", C.c_void_p), ("scale", C.c_void_p), ("packed", C.c_void_p),
+                ("kind", C.c_int32), ("cin_k", C.c_int32), ("cout_k", C.c_int32),
+                ("ksize", C.c_int32)]
+
+
 _P = C.c_void_p
 _AP = C.POINTER(Act)
 _i = C.c_int
@@ -36,6 +44,7 @@ SIGNATURES = {
     "segmi_last_error": (C.c_char_p, []),
     "segmi_wpack_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "segmi_wpack": (_i, [_i, _i, _P, _P, _i, _i, _i, _P, _P]),
+    "segmi_wpack_batch": (_i, [_i, C.POINTER(WpackDesc), _i, _P, _i, _P]),
     "segmi_conv3d_stats_rows": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),

@@ -14,6 +14,7 @@ static inline int stat_vox(int64_t nvox) {
   return v;
 }
 constexpr int kCollapseBlocks = 64;
+constexpr int kDirectRows = 640;   // up to this many partial rows the finalize kernels read them directly
 // rows reserved behind every caller-visible partial buffer for the f64 stage-1 result:
 // 64 blocks x width doubles = 128 rows of `width` floats (+1 for 8-byte alignment)
 constexpr int kReserveRows = 2 * kCollapseBlocks + 1;
@@ -173,9 +174,11 @@ static int collapse_launch(const float* partials, int real_rows, int width, hipS
   return SEGMI_OK;
 }
 
-// collapsed [rows][2][c] f64 -> per-channel statistics (fixed order)
+// [rows][2][c] partials (f64 collapsed rows, or the raw f32 rows when there are few of them) ->
+// per-channel statistics (f64 accumulation, fixed order)
+template <typename IN>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const double* __restrict__ partials, int rows, int c, double count, const float* gamma,
+    const IN* __restrict__ partials, int rows, int c, double count, const float* gamma,
     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
     float* mean, float* invstd, float* scale, float* shift) {
   __shared__ double red[2][256];
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     double s = 0.0, q = 0.0;
     if (part < parts && ch < c) {
       for (int r = part; r < rows; r += parts) {
-        s += partials[((int64_t)r * 2 + 0) * c + ch];
-        q += partials[((int64_t)r * 2 + 1) * c + ch];
+        s += (double)partials[((int64_t)r * 2 + 0) * c + ch];
+        q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
       }
     }
     red[0][tid] = s; red[1][tid] = q;
@@ -326,8 +329,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
 }
 
 // partials -> dgamma, dbeta, dalpha(sum over channels), coef[2][c] = {mean dz, mean dz*xhat}
+template <typename IN>
 __global__ __launch_bounds__(256) void bn_act_bwd_finalize_kernel(
-    const double* __restrict__ partials, int rows, int c, double count, float* dgamma,
+    const IN* __restrict__ partials, int rows, int c, double count, float* dgamma,
     float* dbeta, float* dalpha, float* coef) {
   __shared__ double red[3][256];
   __shared__ double asum[256];
@@ -340,9 +344,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_finalize_kernel(
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     if (part < parts && ch < c) {
       for (int r = part; r < rows; r += parts) {
-        s0 += partials[((int64_t)r * 3 + 0) * c + ch];
-        s1 += partials[((int64_t)r * 3 + 1) * c + ch];
-        s2 += partials[((int64_t)r * 3 + 2) * c + ch];
+        s0 += (double)partials[((int64_t)r * 3 + 0) * c + ch];
+        s1 += (double)partials[((int64_t)r * 3 + 1) * c + ch];
+        s2 += (double)partials[((int64_t)r * 3 + 2) * c + ch];
       }
     }
     red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
@@ -488,13 +492,19 @@ int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count
                       scale && shift,
                   "bn_finalize: bad arguments (rows must come from a *_stats_rows() call)");
   const int real = rows - kReserveRows;
-  const int rc = collapse_launch(stats_partials, real, 2 * c, (hipStream_t)stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, 1, 256, 0, (hipStream_t)stream,
-                     (const double*)collapse_scratch(stats_partials, real, 2 * c),
-                     kCollapseBlocks, c,
-                     count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                     scale, shift);
+  if (real <= kDirectRows) {   // few rows: one launch, no stage-1 collapse
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, 1, 256, 0, (hipStream_t)stream, stats_partials,
+                       real, c, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                       invstd, scale, shift);
+  } else {
+    const int rc = collapse_launch(stats_partials, real, 2 * c, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, 1, 256, 0, (hipStream_t)stream,
+                       (const double*)collapse_scratch(stats_partials, real, 2 * c),
+                       kCollapseBlocks, c,
+                       count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                       scale, shift);
+  }
   SEGMI_LAUNCH_CHECK("bn_finalize");
   return SEGMI_OK;
 }
@@ -562,12 +572,17 @@ int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double
   SEGMI_CHECK_ARG(red_partials && rows > kReserveRows && c > 0 && count > 0 && coef,
                   "bn_act_bwd_finalize: bad arguments (rows must come from bn_act_bwd_rows())");
   const int real = rows - kReserveRows;
-  const int rc = collapse_launch(red_partials, real, 3 * c, (hipStream_t)stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, 1, 256, 0, (hipStream_t)stream,
-                     (const double*)collapse_scratch(red_partials, real, 3 * c),
-                     kCollapseBlocks, c, count, dgamma, dbeta,
-                     dalpha, coef);
+  if (real <= kDirectRows) {
+    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel<float>, 1, 256, 0, (hipStream_t)stream,
+                       red_partials, real, c, count, dgamma, dbeta, dalpha, coef);
+  } else {
+    const int rc = collapse_launch(red_partials, real, 3 * c, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel<double>, 1, 256, 0, (hipStream_t)stream,
+                       (const double*)collapse_scratch(red_partials, real, 3 * c),
+                       kCollapseBlocks, c, count, dgamma, dbeta,
+                       dalpha, coef);
+  }
   SEGMI_LAUNCH_CHECK("bn_act_bwd_finalize");
   return SEGMI_OK;
 }

@@ -77,6 +77,74 @@ __global__ void wpack_convT_kernel(const float* __restrict__ w, const float* __r
   }
 }
 
+// Batched packing: blockIdx.y selects a descriptor (device table), one launch re-packs every
+// convolution of the network after an optimiser step (46 launches -> 1).
+template <typename T>
+__global__ void wpack_batch_kernel(const segmi_wpack_desc* __restrict__ descs) {
+  constexpr int KG = Elem<T>::KG;
+  const segmi_wpack_desc d = descs[blockIdx.y];
+  const int CK = (sizeof(T) == 2 && d.cin_k % 32 == 0) ? 32 : 16;
+  const int SPT = CK / KG;
+  const int nchunks = d.cin_k / CK, ntiles = d.cout_k / 16;
+  const float* w = d.w_src;
+  const float* scale = d.scale;
+  T* out = (T*)d.packed;
+  if (d.kind == 2) {
+    int64_t base = 0;
+    for (int p = 0; p < 8; ++p) {
+      const int nt_p = ct_ntaps(p);
+      const int nsteps = (nt_p * SPT + 3) / 4;
+      const int64_t total = (int64_t)nchunks * nsteps * ntiles * 64 * KG;
+      for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+           e += (int64_t)gridDim.x * blockDim.x) {
+        int j = e % KG;
+        int64_t r = e / KG;
+        int lane = r % 64; r /= 64;
+        int nt = r % ntiles; r /= ntiles;
+        int s = r % nsteps;
+        int c = r / nsteps;
+        int q = 4 * s + (lane >> 4);
+        int tap = q / SPT, sub = q % SPT;
+        int ch = c * CK + sub * KG + j;
+        int co = nt * 16 + (lane & 15);
+        float v = 0.f;
+        if (tap < nt_p) {
+          int kd, kh, kw, dd, dh, dw;
+          ct_tap(p, tap, kd, kh, kw, dd, dh, dw);
+          v = w[((int64_t)ch * d.cout_k + co) * 27 + (kd * 3 + kh) * 3 + kw];
+          if (scale) v *= scale[co];
+        }
+        Elem<T>::st(out + base + e, v);
+      }
+      base += total;
+    }
+  } else {
+    const int ntaps = d.ksize * d.ksize * d.ksize;
+    const int nsteps = (ntaps * SPT + 3) / 4;
+    const int64_t total = (int64_t)nchunks * nsteps * ntiles * 64 * KG;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+      int j = e % KG;
+      int64_t r = e / KG;
+      int lane = r % 64; r /= 64;
+      int nt = r % ntiles; r /= ntiles;
+      int s = r % nsteps;
+      int c = r / nsteps;
+      int q = 4 * s + (lane >> 4);
+      int tap = q / SPT, sub = q % SPT;
+      int ch = c * CK + sub * KG + j;
+      int co = nt * 16 + (lane & 15);
+      float v = 0.f;
+      if (tap < ntaps) {
+        if (d.kind == 0) v = w[((int64_t)co * d.cin_k + ch) * ntaps + tap];
+        else v = w[((int64_t)ch * d.cout_k + co) * ntaps + (ntaps - 1 - tap)];
+        if (scale) v *= scale[co];
+      }
+      Elem<T>::st(out + e, v);
+    }
+  }
+}
+
 static int64_t wpack_elems(int dtype, int kind, int cin, int cout, int ksize) {
   if (kind == 2) {
     PackGeom g = pack_geom(dtype, cin, cout, 1);
@@ -136,6 +204,38 @@ int segmi_wpack(int dtype, int kind, const float* w_src, const float* scale, int
                          g.ntiles, total);
   }
   SEGMI_LAUNCH_CHECK("wpack");
+  return SEGMI_OK;
+}
+
+int segmi_wpack_batch(int dtype, const segmi_wpack_desc* descs_host, int ndesc,
+                      segmi_wpack_desc* descs_dev, int upload, void* stream) {
+  SEGMI_CHECK_ARG(descs_host && descs_dev, "wpack_batch: null descriptor table");
+  SEGMI_CHECK_ARG(ndesc > 0 && ndesc <= 65535, "wpack_batch: ndesc %d out of range", ndesc);
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "wpack_batch: bad dtype %d", dtype);
+  for (int i = 0; i < ndesc; ++i) {
+    const segmi_wpack_desc& d = descs_host[i];
+    SEGMI_CHECK_ARG(d.w_src && d.packed, "wpack_batch[%d]: null pointer", i);
+    SEGMI_CHECK_ARG(d.cin_k > 0 && d.cout_k > 0 && d.cin_k % 16 == 0 && d.cout_k % 16 == 0,
+                    "wpack_batch[%d]: MFMA packs need cin %% 16 == 0 and cout %% 16 == 0", i);
+    SEGMI_CHECK_ARG(d.kind >= 0 && d.kind <= 2, "wpack_batch[%d]: bad kind %d", i, d.kind);
+    SEGMI_CHECK_ARG(d.ksize == 1 || d.ksize == 3, "wpack_batch[%d]: ksize must be 1 or 3", i);
+    SEGMI_CHECK_ARG(d.kind != 2 || d.ksize == 3, "wpack_batch[%d]: transposed conv is k3 only", i);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (upload) {
+    hipError_t e = hipMemcpyAsync(descs_dev, descs_host, sizeof(segmi_wpack_desc) * ndesc,
+                                  hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+      set_error("wpack_batch: descriptor upload failed: %s", hipGetErrorString(e));
+      return SEGMI_ELAUNCH;
+    }
+  }
+  dim3 grid(64, ndesc);
+  if (dtype == SEGMI_F32)
+    hipLaunchKernelGGL(wpack_batch_kernel<float>, grid, 256, 0, st, descs_dev);
+  else
+    hipLaunchKernelGGL(wpack_batch_kernel<bf16_t>, grid, 256, 0, st, descs_dev);
+  SEGMI_LAUNCH_CHECK("wpack_batch");
   return SEGMI_OK;
 }
 

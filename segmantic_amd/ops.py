@@ -71,6 +71,40 @@ def wpack_bytes(dtype: torch.dtype, kind: int, cin_k: int, cout_k: int, ksize: i
     return int(lib.segmi_wpack_bytes(_DT[dtype], kind, cin_k, cout_k, ksize))
 
 
+class WpackBatch:
+    """Descriptor table for ``segmi_wpack_batch``: built once, re-run after every weight update.
+
+    ``entries`` = [(kind, w_src, scale_or_None, cin_k, cout_k, ksize), ...]; ``self.packed[i]``
+    is the device buffer entry ``i`` writes."""
+
+    def __init__(self, dtype: torch.dtype, entries):
+        self.dtype = dtype
+        self.n = len(entries)
+        self.packed = []
+        self._keep = []
+        self._host = (_lib.WpackDesc * self.n)()
+        dev = entries[0][1].device
+        for i, (kind, w, scale, cin_k, cout_k, ks) in enumerate(entries):
+            nbytes = wpack_bytes(dtype, kind, cin_k, cout_k, ks)
+            if nbytes <= 0:
+                raise ValueError(f"no MFMA pack for cin={cin_k} cout={cout_k}")
+            out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.packed.append(out)
+            self._keep.append((w, scale))
+            d = self._host[i]
+            _require_device(w)
+            d.w_src, d.packed = w.data_ptr(), out.data_ptr()
+            d.scale = scale.data_ptr() if scale is not None else None
+            d.kind, d.cin_k, d.cout_k, d.ksize = kind, cin_k, cout_k, ks
+        self._dev = torch.empty(C.sizeof(_lib.WpackDesc) * self.n, dtype=torch.uint8, device=dev)
+        self._uploaded = False
+
+    def run(self):
+        check(lib.segmi_wpack_batch(_DT[self.dtype], self._host, self.n, _ptr(self._dev),
+                                    0 if self._uploaded else 1, _stream()), "wpack_batch")
+        self._uploaded = True
+
+
 def wpack(dtype: torch.dtype, kind: int, w_src: torch.Tensor, cin_k: int, cout_k: int,
           ksize: int, scale: Optional[torch.Tensor] = None,
           out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -100,6 +100,15 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
 
 def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_ids,
         ckpt_name: Callable, batch_volumes: int = 2, seed: int = 0):
+    if net.augment_intensity or net.augment_spatial:
+        raise NotImplementedError(
+            "segmantic_amd: 'augment_intensity' / 'augment_spatial' (MONAI RandRotate/RandZoom/"
+            "intensity transforms, reference monai_unet.py:181-212) are not implemented on the GPU "
+            "sampler yet; the default crop + flip augmentation is")
+    if len(list(gpu_ids or [0])) > 1 and env_world()[2] == 1:
+        raise RuntimeError(
+            "segmantic_amd: several gpu_ids need one process per GPU: launch with "
+            "`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ...`")
     rank, local_rank, world = init_distributed()
     ids = list(gpu_ids) if gpu_ids else [0]
     dev_index = ids[local_rank % len(ids)] if world > 1 else ids[0]

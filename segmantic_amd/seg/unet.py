@@ -150,6 +150,7 @@ class _Conv:
         self.gb = eng.grad(prefix + ".bias")
         self._packs: Dict[tuple, Tuple[int, Optional[torch.Tensor]]] = {}
         self._fold: Dict[str, tuple] = {}
+        eng._convs.append(self)
 
     @property
     def mfma(self) -> bool:
@@ -160,6 +161,8 @@ class _Conv:
             return None
         key = (tag, self.eng.dtype)
         ver = self.eng.weights_version
+        if self.eng._packed_version != ver:
+            self.eng._repack_all()
         hit = self._packs.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -168,19 +171,25 @@ class _Conv:
         self._packs[key] = (ver, buf)
         return buf
 
-    # forward operand
-    def fwd_pack(self):
+    # forward operand: (kind, cin_k, cout_k, ksize)
+    def fwd_geom(self):
         if self.transposed:
-            return self._pack("fwd", 2, self.cin, self.cout, 3)
-        return self._pack("fwd", 0, self.cin, self.cout, self.k)
+            return (2, self.cin, self.cout, 3)
+        return (0, self.cin, self.cout, self.k)
 
     # input-gradient operand (the kernel that consumes it sees cin_k = cout, cout_k = cin)
-    def dgrad_pack(self):
+    def dgrad_geom(self):
         if self.transposed:   # dgrad of convT = stride-2 conv over dy with the weight as is
-            return self._pack("dgrad", 0, self.cout, self.cin, 3)
+            return (0, self.cout, self.cin, 3)
         if self.stride == 2:  # dgrad of a stride-2 conv = transposed-conv kernel, weight as is
-            return self._pack("dgrad", 2, self.cout, self.cin, 3)
-        return self._pack("dgrad", 1, self.cout, self.cin, self.k)
+            return (2, self.cout, self.cin, 3)
+        return (1, self.cout, self.cin, self.k)
+
+    def fwd_pack(self):
+        return self._pack("fwd", *self.fwd_geom())
+
+    def dgrad_pack(self):
+        return self._pack("dgrad", *self.dgrad_geom())
 
     # eval mode: BatchNorm folded into the weights (scale) and bias
     def folded(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]):
@@ -255,6 +264,9 @@ class UNetEngine:
         self.device = torch.device(device)
         self.dtype = dtype
         self.weights_version = 0
+        self._packed_version = -1
+        self._convs: list = []
+        self._wbatch = None
         self.training = True
         self._bufs: Dict[str, torch.Tensor] = {}
         self._scratch: Dict[str, torch.Tensor] = {}
@@ -304,6 +316,27 @@ class UNetEngine:
                 tgt.copy_(b.data.to(self.device))
                 b.data = tgt
         self.weights_version += 1
+
+    def _repack_all(self):
+        """One ``segmi_wpack_batch`` launch refreshes the forward and input-gradient operand of
+        every MFMA convolution for the current ``weights_version``."""
+        ver = self.weights_version
+        if self._wbatch is None:
+            entries, slots = [], []
+            for conv in self._convs:
+                if not conv.mfma:
+                    continue
+                for tag, geom in (("fwd", conv.fwd_geom()), ("dgrad", conv.dgrad_geom())):
+                    kind, cin_k, cout_k, k = geom
+                    entries.append((kind, conv.w, None, cin_k, cout_k, k))
+                    slots.append((conv, (tag, self.dtype)))
+            self._wbatch = (ops.WpackBatch(self.dtype, entries), slots) if entries else (None, [])
+        batch, slots = self._wbatch
+        if batch is not None:
+            batch.run()
+            for (conv, key), buf in zip(slots, batch.packed):
+                conv._packs[key] = (ver, buf)
+        self._packed_version = ver
 
     def param(self, key):
         return self._pviews["model." + key]

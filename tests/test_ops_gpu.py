@@ -165,6 +165,31 @@ CONVT_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wpack_batch_is_bit_identical_to_single_packs(dtype):
+    """One batched launch (every layer, every kind) == the per-layer packs, byte for byte."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    entries, singles = [], []
+    for kind, cin, cout, k, scaled in [(0, 16, 32, 3, False), (1, 32, 16, 3, False), (0, 64, 16, 1, True),
+                                       (2, 32, 16, 3, False), (2, 48, 32, 3, True), (1, 16, 16, 1, False),
+                                       (0, 256, 128, 3, False)]:
+        if kind == 0:
+            w = torch.randn(cout, cin, k, k, k, generator=g).to(DEV)
+        else:   # kinds 1/2 read [cin][cout][taps]
+            w = torch.randn(cin, cout, k, k, k, generator=g).to(DEV)
+        sc = (torch.rand(cout, generator=g) + 0.5).to(DEV) if scaled else None
+        entries.append((kind, w, sc, cin, cout, k))
+        singles.append(ops.wpack(dtype, kind, w, cin, cout, k, scale=sc))
+    batch = ops.WpackBatch(dtype, entries)
+    for rep in range(2):          # second run re-uses the uploaded table
+        for buf in batch.packed:
+            buf.fill_(0xAB)
+        batch.run()
+        torch.cuda.synchronize()
+        for got, want in zip(batch.packed, singles):
+            assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONVT_CASES)
 def test_convT3d_fwd(case, dtype):
     cin, cout, sp, n, odd = case
