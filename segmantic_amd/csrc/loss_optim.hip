@@ -3,12 +3,12 @@
 // 16-byte vectors along the class axis (NDHWC keeps the K classes of a voxel contiguous), the
 // softmax lives in registers, reductions are two-stage and deterministic.
 #include "common.h"
+#include "reduce_fin.h"
 
 namespace segmi {
 
 constexpr int kDiceVox = 8192;  // voxels per workgroup
 
-int collapse_rows_into(const float* partials, int rows, int width, double* out, hipStream_t st);
 
 struct DiceParams {
   const void* logits;
@@ -109,37 +109,36 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
 }
 
 // one block: per (n,k) sums of the collapsed rows (f64), loss + backward coefficients
-__global__ __launch_bounds__(256) void dice_finalize_kernel(const double* __restrict__ partials,
-                                                            int n, int k, int chunks,
-                                                            float smooth_nr, float smooth_dr,
-                                                            float* coef, float* loss) {
-  __shared__ double fsum[256];
-  const int tid = threadIdx.x;
-  double local = 0.0;
-  const double nk = (double)n * k;
-  for (int o = tid; o < n * k; o += 256) {
-    const int b = o / k, j = o % k;
-    double I = 0.0, P = 0.0, Tt = 0.0;
-    for (int c = 0; c < chunks; ++c) {
-      const double* q = partials + (((int64_t)c * n + b) * 3) * k + j;
-      I += q[0]; P += q[k]; Tt += q[2 * k];
+struct DiceFin {
+  int n, k;
+  float smooth_nr, smooth_dr;
+  float *coef, *loss;
+  // sums: [n][3][k] = {intersection, sum p, sum t}
+  __device__ void operator()(const double* sums, double* red) const {
+    const int tid = threadIdx.x;
+    double local = 0.0;
+    const double nk = (double)n * k;
+    for (int o = tid; o < n * k; o += 256) {
+      const int b = o / k, j = o % k;
+      const double* q = sums + ((int64_t)b * 3) * k + j;
+      const double I = q[0], P = q[k], Tt = q[2 * k];
+      // f32 arithmetic as the reference does on the reduced sums
+      const float If = (float)I, Df = (float)Tt + (float)P;
+      const float f = 1.0f - (2.0f * If + smooth_nr) / (Df + smooth_dr);
+      local += (double)f;
+      const double den = (double)Df + (double)smooth_dr;
+      coef[((int64_t)b * 2 + 0) * k + j] = (float)(-2.0 / den / nk);
+      coef[((int64_t)b * 2 + 1) * k + j] = (float)((2.0 * (double)If + (double)smooth_nr) / (den * den) / nk);
     }
-    // f32 arithmetic as the reference does on the reduced sums
-    const float If = (float)I, Df = (float)Tt + (float)P;
-    const float f = 1.0f - (2.0f * If + smooth_nr) / (Df + smooth_dr);
-    local += (double)f;
-    const double den = (double)Df + (double)smooth_dr;
-    coef[((int64_t)b * 2 + 0) * k + j] = (float)(-2.0 / den / nk);
-    coef[((int64_t)b * 2 + 1) * k + j] = (float)((2.0 * (double)If + (double)smooth_nr) / (den * den) / nk);
+    red[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int i = 0; i < 256; ++i) t += red[i];
+      *loss = (float)(t / nk);
+    }
   }
-  fsum[tid] = local;
-  __syncthreads();
-  if (tid == 0) {
-    double t = 0.0;
-    for (int i = 0; i < 256; ++i) t += fsum[i];
-    *loss = (float)(t / nk);
-  }
-}
+};
 
 template <typename T, int KMAX>
 __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
@@ -281,11 +280,11 @@ static inline int dice_real_chunks(const segmi_act* logits) {
   return (int)cdiv64((int64_t)logits->d * logits->h * logits->w, kDiceVox);
 }
 
-// chunks the caller must allocate: the real ones + a 129-chunk tail that holds the f64 stage-1
-// reduction (64 x [n][3][k] doubles), same scheme as the *_stats_rows() queries
+// chunks the caller must allocate: the real ones + a tail that holds the f64 stage-1 reduction
+// of reduce_fin.h (65 x [n][3][k] doubles), same scheme as the *_stats_rows() queries
 int segmi_dice_chunks(const segmi_act* logits) {
   if (!logits) return 0;
-  return dice_real_chunks(logits) + 129;
+  return dice_real_chunks(logits) + 2 * kFinScratchRows + 1;
 }
 
 int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labels,
@@ -303,14 +302,9 @@ int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labe
                               : dice_dispatch<bf16_t>(true, p, st);
   if (rc) return rc;
   const int width = p.n * 3 * p.k;
-  uintptr_t tail = (uintptr_t)(partials + (int64_t)p.chunks * width);
-  double* col = (double*)((tail + 7) & ~(uintptr_t)7);
-  rc = collapse_rows_into(partials, p.chunks, width, col, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(dice_finalize_kernel, 1, 256, 0, st, (const double*)col, p.n, p.k, 64,
-                     smooth_nr, smooth_dr, coef, loss);
-  SEGMI_LAUNCH_CHECK("softmax_dice_fwd(finalize)");
-  return SEGMI_OK;
+  const DiceFin fin{p.n, p.k, smooth_nr, smooth_dr, coef, loss};
+  return collapse_fin_launch(partials, p.chunks, width, fin_scratch(partials, p.chunks, width), st,
+                             fin, "softmax_dice_fwd(finalize)");
 }
 
 int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labels,

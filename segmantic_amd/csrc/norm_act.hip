@@ -3,6 +3,7 @@
 // channel axis, per-channel parameters cached in LDS, deterministic two-stage reductions
 // (per-workgroup partials in f32, final reduce in f64) -- no float atomics anywhere.
 #include "common.h"
+#include "reduce_fin.h"
 
 namespace segmi {
 
@@ -13,11 +14,9 @@ static inline int stat_vox(int64_t nvox) {
   while (v > 64 && nvox / v < 512) v >>= 1;
   return v;
 }
-constexpr int kCollapseBlocks = 64;
-constexpr int kDirectRows = 640;   // up to this many partial rows the finalize kernels read them directly
-// rows reserved behind every caller-visible partial buffer for the f64 stage-1 result:
-// 64 blocks x width doubles = 128 rows of `width` floats (+1 for 8-byte alignment)
-constexpr int kReserveRows = 2 * kCollapseBlocks + 1;
+// rows reserved behind every caller-visible partial buffer for the f64 stage-1 result of
+// reduce_fin.h: 65 rows of `width` doubles = 130 rows of `width` floats (+1 for 8-byte alignment)
+constexpr int kReserveRows = 2 * kFinScratchRows + 1;
 
 int bn_stats_rows_for(const segmi_act* x) {
   return (int)cdiv64(act_voxels(x), stat_vox(act_voxels(x)));
@@ -131,79 +130,20 @@ int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t 
   return SEGMI_OK;
 }
 
-// Stage 1 of every partial-row reduction: [rows][width] f32 -> [kCollapseBlocks][width] f64,
-// fixed order (block b owns rows b*rl + lane, stepping by nblk*rl).  The f64 result lives in a
-// scratch tail that the *_rows() entry points reserve behind the caller's partial buffer.
-__global__ __launch_bounds__(256) void collapse_rows_kernel(const float* __restrict__ in, int rows,
-                                                            int width, double* __restrict__ out) {
-  __shared__ double red[256];
-  const int wl = width < 256 ? width : 256;
-  const int rl = 256 / wl;
-  const int tid = threadIdx.x;
-  for (int w0 = 0; w0 < width; w0 += wl) {
-    const int e = w0 + tid % wl, lane = tid / wl;
-    double s = 0.0;
-    if (lane < rl && e < width)
-      for (int r = blockIdx.x * rl + lane; r < rows; r += gridDim.x * rl)
-        s += (double)in[(int64_t)r * width + e];
-    red[tid] = s;
-    __syncthreads();
-    if (tid < wl && w0 + tid < width) {
-      double t = 0.0;
-      for (int l = 0; l < rl; ++l) t += red[l * wl + tid];
-      out[(int64_t)blockIdx.x * width + w0 + tid] = t;
-    }
-    __syncthreads();
-  }
-}
-
-static inline double* collapse_scratch(const float* partials, int real_rows, int width) {
-  uintptr_t p = (uintptr_t)(partials + (int64_t)real_rows * width);
-  return (double*)((p + 7) & ~(uintptr_t)7);
-}
-// shared with loss_optim.hip / wgrad.hip: collapse [rows][width] f32 into `out` [64][width] f64
-int collapse_rows_into(const float* partials, int rows, int width, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(collapse_rows_kernel, kCollapseBlocks, 256, 0, st, partials, rows, width, out);
-  SEGMI_LAUNCH_CHECK("collapse_rows");
-  return SEGMI_OK;
-}
-static int collapse_launch(const float* partials, int real_rows, int width, hipStream_t st) {
-  hipLaunchKernelGGL(collapse_rows_kernel, kCollapseBlocks, 256, 0, st, partials, real_rows, width,
-                     collapse_scratch(partials, real_rows, width));
-  SEGMI_LAUNCH_CHECK("collapse_rows");
-  return SEGMI_OK;
-}
-
-// [rows][2][c] partials (f64 collapsed rows, or the raw f32 rows when there are few of them) ->
-// per-channel statistics (f64 accumulation, fixed order)
-template <typename IN>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const IN* __restrict__ partials, int rows, int c, double count, const float* gamma,
-    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-    float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][256];
-  const int cp = c < 256 ? c : 256;
-  const int parts = 256 / cp;
-  const int tid = threadIdx.x;
-  for (int c0 = 0; c0 < c; c0 += cp) {
-    const int ch = c0 + tid % cp, part = tid / cp;
-    double s = 0.0, q = 0.0;
-    if (part < parts && ch < c) {
-      for (int r = part; r < rows; r += parts) {
-        s += (double)partials[((int64_t)r * 2 + 0) * c + ch];
-        q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
-      }
-    }
-    red[0][tid] = s; red[1][tid] = q;
-    __syncthreads();
-    if (tid < cp && c0 + tid < c) {
-      double ss = 0.0, qq = 0.0;
-      for (int pi = 0; pi < parts; ++pi) { ss += red[0][pi * cp + tid]; qq += red[1][pi * cp + tid]; }
-      const double m = ss / count;
-      double var = qq / count - m * m;
+// [2][c] column sums -> per-channel statistics (the second stage of reduce_fin.h)
+struct BnFin {
+  int c;
+  double count;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  float momentum, eps;
+  float *mean, *invstd, *scale, *shift;
+  __device__ void operator()(const double* sums, double*) const {
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
+      const double m = sums[cc] / count;
+      double var = sums[c + cc] / count - m * m;
       if (var < 0.0) var = 0.0;
       const float is = (float)(1.0 / sqrt(var + (double)eps));
-      const int cc = c0 + tid;
       mean[cc] = (float)m;
       invstd[cc] = is;
       const float sc = (gamma ? gamma[cc] : 1.f) * is;
@@ -215,9 +155,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * (float)unb;
       }
     }
-    __syncthreads();
   }
-}
+};
 
 __global__ void bn_eval_affine_kernel(int c, const float* gamma, const float* beta,
                                       const float* rm, const float* rv, float eps, float* scale,
@@ -328,51 +267,32 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
   }
 }
 
-// partials -> dgamma, dbeta, dalpha(sum over channels), coef[2][c] = {mean dz, mean dz*xhat}
-template <typename IN>
-__global__ __launch_bounds__(256) void bn_act_bwd_finalize_kernel(
-    const IN* __restrict__ partials, int rows, int c, double count, float* dgamma,
-    float* dbeta, float* dalpha, float* coef) {
-  __shared__ double red[3][256];
-  __shared__ double asum[256];
-  const int cp = c < 256 ? c : 256;
-  const int parts = 256 / cp;
-  const int tid = threadIdx.x;
-  double alpha_acc = 0.0;
-  for (int c0 = 0; c0 < c; c0 += cp) {
-    const int ch = c0 + tid % cp, part = tid / cp;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    if (part < parts && ch < c) {
-      for (int r = part; r < rows; r += parts) {
-        s0 += (double)partials[((int64_t)r * 3 + 0) * c + ch];
-        s1 += (double)partials[((int64_t)r * 3 + 1) * c + ch];
-        s2 += (double)partials[((int64_t)r * 3 + 2) * c + ch];
-      }
-    }
-    red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
-    __syncthreads();
-    if (tid < cp && c0 + tid < c) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int pi = 0; pi < parts; ++pi) {
-        a0 += red[0][pi * cp + tid]; a1 += red[1][pi * cp + tid]; a2 += red[2][pi * cp + tid];
-      }
-      const int cc = c0 + tid;
+// [3][c] column sums -> dgamma, dbeta, dalpha (sum over channels), coef[2][c] = {mean dz, mean dz*xhat}
+struct BnBwdFin {
+  int c;
+  double count;
+  float *dgamma, *dbeta, *dalpha, *coef;
+  __device__ void operator()(const double* sums, double* red) const {
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
+      const double a0 = sums[cc], a1 = sums[c + cc];
       if (dbeta) dbeta[cc] = (float)a0;
       if (dgamma) dgamma[cc] = (float)a1;
       coef[cc] = (float)(a0 / count);
       coef[c + cc] = (float)(a1 / count);
-      alpha_acc += a2;
     }
-    __syncthreads();
+    if (dalpha) {   // fixed-order sum over channels
+      double t = 0.0;
+      for (int cc = threadIdx.x; cc < c; cc += 256) t += sums[2 * c + cc];
+      red[threadIdx.x] = t;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int i = 0; i < 256; ++i) a += red[i];
+        *dalpha = (float)a;
+      }
+    }
   }
-  asum[tid] = alpha_acc;
-  __syncthreads();
-  if (tid == 0 && dalpha) {
-    double t = 0.0;
-    for (int i = 0; i < 256; ++i) t += asum[i];
-    *dalpha = (float)t;
-  }
-}
+};
 
 // dx = gamma*invstd*(dz - c0 - xhat*c1)
 template <typename T, int VEC>
@@ -492,21 +412,10 @@ int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count
                       scale && shift,
                   "bn_finalize: bad arguments (rows must come from a *_stats_rows() call)");
   const int real = rows - kReserveRows;
-  if (real <= kDirectRows) {   // few rows: one launch, no stage-1 collapse
-    hipLaunchKernelGGL(bn_finalize_kernel<float>, 1, 256, 0, (hipStream_t)stream, stats_partials,
-                       real, c, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
-                       invstd, scale, shift);
-  } else {
-    const int rc = collapse_launch(stats_partials, real, 2 * c, (hipStream_t)stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, 1, 256, 0, (hipStream_t)stream,
-                       (const double*)collapse_scratch(stats_partials, real, 2 * c),
-                       kCollapseBlocks, c,
-                       count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                       scale, shift);
-  }
-  SEGMI_LAUNCH_CHECK("bn_finalize");
-  return SEGMI_OK;
+  const BnFin fin{c, count, gamma, beta, running_mean, running_var, momentum, eps,
+                  mean, invstd, scale, shift};
+  return collapse_fin_launch(stats_partials, real, 2 * c, fin_scratch(stats_partials, real, 2 * c),
+                             (hipStream_t)stream, fin, "bn_finalize");
 }
 
 int segmi_bn_eval_affine(int c, const float* gamma, const float* beta,
@@ -572,19 +481,9 @@ int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double
   SEGMI_CHECK_ARG(red_partials && rows > kReserveRows && c > 0 && count > 0 && coef,
                   "bn_act_bwd_finalize: bad arguments (rows must come from bn_act_bwd_rows())");
   const int real = rows - kReserveRows;
-  if (real <= kDirectRows) {
-    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel<float>, 1, 256, 0, (hipStream_t)stream,
-                       red_partials, real, c, count, dgamma, dbeta, dalpha, coef);
-  } else {
-    const int rc = collapse_launch(red_partials, real, 3 * c, (hipStream_t)stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel<double>, 1, 256, 0, (hipStream_t)stream,
-                       (const double*)collapse_scratch(red_partials, real, 3 * c),
-                       kCollapseBlocks, c, count, dgamma, dbeta,
-                       dalpha, coef);
-  }
-  SEGMI_LAUNCH_CHECK("bn_act_bwd_finalize");
-  return SEGMI_OK;
+  const BnBwdFin fin{c, count, dgamma, dbeta, dalpha, coef};
+  return collapse_fin_launch(red_partials, real, 3 * c, fin_scratch(red_partials, real, 3 * c),
+                             (hipStream_t)stream, fin, "bn_act_bwd_finalize");
 }
 
 int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,

@@ -1,0 +1,130 @@
+// reduce_fin.h -- one-launch, fixed-order reduction of a table of f32 partial rows followed by a
+// caller-supplied finalisation.
+//
+//   stage 1: `nblk` (<= 64) workgroups each fold a fixed subset of the [rows][width] f32 table into
+//            one f64 row of `scratch` ([nblk][width] doubles).
+//   stage 2: the workgroup that takes the last ticket folds the nblk f64 rows (fixed order) into
+//            `width` column sums held in LDS and runs `fin(sums)` with all 256 threads.
+//
+// The result does not depend on which workgroup arrives last: both stages add in an order fixed by
+// (rows, width, nblk) only, so the reduction is deterministic without float atomics.  The ticket
+// counters are integers, self-resetting, and handed out round-robin by the host so two launches in
+// flight (main + side stream) never share one.
+#pragma once
+#include <atomic>
+
+#include "common.h"
+
+namespace segmi {
+
+constexpr int kFinBlocks = 64;      // stage-1 rows; the scratch behind a partial table holds these
+constexpr int kFinTickets = 2048;
+constexpr int kFinLdsWidth = 4096;  // up to 32 KB of f64 column sums live in LDS; wider tables
+                                    // keep them in one more scratch row
+constexpr int kFinScratchRows = kFinBlocks + 1;   // f64 rows of `width` behind a partial table
+
+static __device__ unsigned int g_fin_tickets[kFinTickets];
+static std::atomic<unsigned> g_fin_next{0};
+
+static inline int fin_blocks(int rows) {
+  int b = rows / 8;
+  return b < 1 ? 1 : (b > kFinBlocks ? kFinBlocks : b);
+}
+
+template <class Fin>
+__global__ __launch_bounds__(256) void collapse_fin_kernel(const float* __restrict__ in, int rows,
+                                                           int width, double* scratch,
+                                                           unsigned ticket, Fin fin) {
+  extern __shared__ double fin_lds[];   // [width] when width <= kFinLdsWidth
+  double* fin_sums = width <= kFinLdsWidth ? fin_lds : scratch + (int64_t)kFinBlocks * width;
+  __shared__ double red[256];
+  __shared__ int s_last;
+  const int wl = width < 256 ? width : 256;
+  const int rl = 256 / wl;
+  const int tid = threadIdx.x;
+  const int col = tid % wl, lane = tid / wl;
+  const int nblk = gridDim.x;
+  for (int w0 = 0; w0 < width; w0 += wl) {
+    const int e = w0 + col;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (lane < rl && e < width) {
+      const int step = nblk * rl;
+      int r = blockIdx.x * rl + lane;
+      for (; r + 3 * step < rows; r += 4 * step) {
+        s0 += (double)in[(int64_t)r * width + e];
+        s1 += (double)in[(int64_t)(r + step) * width + e];
+        s2 += (double)in[(int64_t)(r + 2 * step) * width + e];
+        s3 += (double)in[(int64_t)(r + 3 * step) * width + e];
+      }
+      for (; r < rows; r += step) s0 += (double)in[(int64_t)r * width + e];
+    }
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (tid < wl && w0 + tid < width) {
+      double t = 0.0;
+      for (int l = 0; l < rl; ++l) t += red[l * wl + tid];
+      if (nblk == 1) fin_sums[w0 + tid] = t;
+      else scratch[(int64_t)blockIdx.x * width + w0 + tid] = t;
+    }
+    __syncthreads();
+  }
+  if (nblk > 1) {
+    __threadfence();   // release: this block's scratch row is visible device-wide (all XCDs)
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = atomicAdd(&g_fin_tickets[ticket], 1u);
+      s_last = prev == (unsigned)nblk - 1;
+      if (s_last) g_fin_tickets[ticket] = 0;   // ready for the next launch that draws this ticket
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();   // acquire: the other blocks' rows
+    const double* t = scratch;
+    for (int w0 = 0; w0 < width; w0 += wl) {
+      const int e = w0 + col;
+      double s0 = 0.0, s1 = 0.0;
+      if (lane < rl && e < width) {
+        int r = lane;
+        for (; r + rl < nblk; r += 2 * rl) {
+          s0 += t[(int64_t)r * width + e];
+          s1 += t[(int64_t)(r + rl) * width + e];
+        }
+        for (; r < nblk; r += rl) s0 += t[(int64_t)r * width + e];
+      }
+      red[tid] = s0 + s1;
+      __syncthreads();
+      if (tid < wl && w0 + tid < width) {
+        double a = 0.0;
+        for (int l = 0; l < rl; ++l) a += red[l * wl + tid];
+        fin_sums[w0 + tid] = a;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  fin(fin_sums, red);
+}
+
+// scratch: >= kFinScratchRows * width doubles, 8-byte aligned
+template <class Fin>
+static inline int collapse_fin_launch(const float* partials, int rows, int width, double* scratch,
+                                      hipStream_t st, const Fin& fin, const char* what) {
+  if (width <= 0 || rows <= 0) {
+    set_error("%s: empty reduction table %d x %d", what, rows, width);
+    return SEGMI_EINVAL;
+  }
+  const unsigned ticket = g_fin_next.fetch_add(1) % kFinTickets;
+  hipLaunchKernelGGL(collapse_fin_kernel<Fin>, fin_blocks(rows), 256,
+                     width <= kFinLdsWidth ? (size_t)width * sizeof(double) : 0,
+                     st, partials, rows, width, scratch, ticket, fin);
+  SEGMI_LAUNCH_CHECK(what);
+  return SEGMI_OK;
+}
+
+// scratch tail behind a caller-visible partial table (the *_rows() queries reserve it)
+static inline double* fin_scratch(const float* partials, int real_rows, int width) {
+  uintptr_t p = (uintptr_t)(partials + (int64_t)real_rows * width);
+  return (double*)((p + 7) & ~(uintptr_t)7);
+}
+
+}  // namespace segmi

@@ -1,5 +1,6 @@
 // wgrad.hip -- weight / bias gradients: C entry points, the direct fallback, slab reduction.
 #include "wgrad_impl.h"
+#include "reduce_fin.h"
 
 namespace segmi {
 
@@ -7,7 +8,6 @@ int wgrad_mfma_f32(const WgradParams& p, int ksize, int stride, int ct, int gx, 
 int wgrad_mfma_bf16(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
 int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
 int bn_stats_rows_for(const segmi_act* x);
-int collapse_rows_into(const float* partials, int rows, int width, double* out, hipStream_t st);
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_wgrad_slabs(const segmi_act* dy);
 int conv_small_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* partials,
@@ -80,14 +80,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partials, int nslab
 }
 
 // collapsed stats [64][2][c] f64 -> db[c] = sum of the "sum" rows (fixed order)
-__global__ void bias_reduce_kernel(const double* __restrict__ col, int rows, int c,
-                                   float* __restrict__ db) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double acc = 0.0;
-  for (int r = 0; r < rows; ++r) acc += col[((int64_t)r * 2) * c + ch];
-  db[ch] = (float)acc;
-}
+struct BiasFin {   // sums: [2][c] = {sum dy, sum dy^2}; the bias gradient is the first half
+  int c;
+  float* db;
+  __device__ void operator()(const double* sums, double*) const {
+    for (int ch = threadIdx.x; ch < c; ch += 256) db[ch] = (float)sums[ch];
+  }
+};
 
 static inline bool aligned_rows(const segmi_act* a, int dtype) {
   const int es = dtype_size(dtype);
@@ -125,7 +124,7 @@ int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_
   if (!x || !dy) return 0;
   const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
   const int slabs = wg_slabs(dtype, x, dy, ksize, stride);
-  const int64_t bias = ((int64_t)bn_stats_rows_for(dy) + 129) * 2 * dy->c * 4;  // + f64 collapse tail
+  const int64_t bias = ((int64_t)bn_stats_rows_for(dy) + 2 * kFinScratchRows + 1) * 2 * dy->c * 4;  // + f64 tail
   return align256(slabs * nout * 4) + align256((int64_t)kSlabGroups * nout * 4) + align256(bias);
 }
 
@@ -135,13 +134,9 @@ int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, 
   int rc = bn_stats_launch(dtype, dy, (float*)workspace, st);
   if (rc) return rc;
   const int rows = bn_stats_rows_for(dy), width = 2 * dy->c;
-  uintptr_t tail = (uintptr_t)((float*)workspace + (int64_t)rows * width);
-  double* col = (double*)((tail + 7) & ~(uintptr_t)7);
-  rc = collapse_rows_into((const float*)workspace, rows, width, col, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bias_reduce_kernel, cdiv(dy->c, 64), 64, 0, st, (const double*)col, 64, dy->c, db);
-  SEGMI_LAUNCH_CHECK("bias_grad");
-  return SEGMI_OK;
+  const BiasFin fin{dy->c, db};
+  return collapse_fin_launch((const float*)workspace, rows, width,
+                             fin_scratch((const float*)workspace, rows, width), st, fin, "bias_grad");
 }
 
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,

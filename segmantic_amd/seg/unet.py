@@ -18,6 +18,7 @@ hand-written gfx950 kernel reached through the C-ABI.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -297,8 +298,16 @@ class UNetEngine:
             self.param_offsets[name] = (off, n)
             off += n
         self._bviews: Dict[str, torch.Tensor] = {}
+        # the int64 ``num_batches_tracked`` counters share one arena: one add per training step
+        nbt = [n for n, _ in self.net.named_buffers() if n.endswith("num_batches_tracked")]
+        self._nbt_flat = torch.zeros(max(len(nbt), 1), dtype=torch.int64, device=self.device)
         for name, b in self.net.named_buffers():
-            b.data = b.data.to(self.device)
+            if name in nbt:
+                view = self._nbt_flat[nbt.index(name)]
+                view.copy_(b.data.to(self.device))
+                b.data = view
+            else:
+                b.data = b.data.to(self.device)
             self._bviews[name] = b.data
         self.num_params = total
 
@@ -435,7 +444,6 @@ class UNetEngine:
             count = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
             ops.bn_finalize(stats, rows, conv.cout, count, bn.gamma, bn.beta, bn.rm, bn.rv,
                             self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
-            bn.nbt += 1
 
     def _wgrad(self, conv: _Conv, x, dy, need_bias: bool = True):
         """dW (and db) of `conv` given its forward input x and output gradient dy.
@@ -693,6 +701,7 @@ class UNetEngine:
         logits = self._buf("logits." + ("t" if train else "e"), (n, d, h, w, self.net.out_channels))
         if train:
             self._saved.clear()
+            self._nbt_flat += 1        # every BatchNorm runs exactly once per training forward
         self._level_fwd(self.levels, xin, logits, train)
         return logits
 
@@ -722,7 +731,8 @@ class UNetEngine:
         return [s.elapsed_time(e) for s, e in self.timings.get(key, [])]
 
     grad_hook = None  # callable(lo_offset): gradients at arena offsets >= lo are final
-    overlap_wgrad = True
+    # SEGMI_SERIAL=1 keeps every kernel on one stream (per-kernel profiling without co-running work)
+    overlap_wgrad = os.environ.get("SEGMI_SERIAL", "0") != "1"
     _side = None
 
     def _side_stream(self):
