@@ -3,7 +3,7 @@
 // tiny test networks).
 #include "conv_fwd_impl.h"
 #include "conv_ring_impl.h"
-#include "convt_fwd_impl.h"
+#include "convt_ps_impl.h"
 
 namespace segmi {
 
@@ -212,7 +212,7 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
 
 int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out) {
   if (!in || !out) return 0;
-  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(dtype, in) + stats_reserve_rows();
+  if (mfma_ok(in->c, out->c)) return convt_mfma_rows(dtype, in, out->c) + stats_reserve_rows();
   return bn_stats_rows_for(out) + stats_reserve_rows();
 }
 

@@ -337,7 +337,7 @@ static int launch_convt_mfma_t(ConvTParams p, hipStream_t st) {
   return launch_convt_nt<T, 16>(p, st);
 }
 
-static inline int convt_mfma_rows(int dtype, const segmi_act* in) {
+static inline int convt_tile_rows(int dtype, const segmi_act* in) {
   const bool wide = in->w > 8;
   const int td = 2, th = wide ? 2 : 4, tw = wide ? 16 : 8;
   (void)dtype;

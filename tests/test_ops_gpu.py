@@ -161,6 +161,9 @@ CONVT_CASES = [
     (16, 16, (3, 5, 17), 1, 1),   # odd output extent (2*in - 1): dgrad of a conv on odd input
     (384, 64, (4, 4, 4), 1, 0),
     (8, 4, (4, 5, 6), 2, 0),      # direct kernel
+    (64, 16, (5, 3, 33), 1, 0),   # persistent kernel, two bf16 chunks, ragged x tiles
+    (32, 16, (3, 4, 16), 2, 1),   # persistent kernel, odd output extent
+    (32, 16, (24, 40, 48), 3, 0), # persistent kernel, several tiles per workgroup + ragged tail
 ]
 
 
@@ -210,6 +213,29 @@ def test_convT3d_fwd(case, dtype):
     ssum = stats[:, 0].double().sum(0).cpu()
     rs = ref.double().sum((0, 2, 3, 4))
     assert float((ssum - rs).abs().max()) / (ref.numel() / cout) < (1e-5 if dtype == torch.float32 else 2e-2) * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(32, 16, (4, 6, 20), 2), (64, 16, (3, 3, 16), 1), (128, 32, (4, 4, 8), 1)])
+def test_convT3d_epilogue_prelu_residual(case, dtype):
+    """PReLU + residual epilogue (the form the dgrad of a stride-2 conv uses) on both kernels."""
+    cin, cout, sp, n = case
+    x = rnd((n, cin) + sp, 24)
+    w = rnd((cin, cout, 3, 3, 3), 25, 1.0 / math.sqrt(cin * 27 / 8))
+    b = rnd((cout,), 26, 0.1)
+    osp = tuple(2 * d for d in sp)
+    res = rnd((n, cout) + osp, 27)
+    alpha = torch.tensor([0.2])
+    ref = F.conv_transpose3d(q(x, dtype), q(w, dtype), b, stride=2, padding=1, output_padding=1)
+    ref = F.prelu(ref, alpha) + q(res, dtype)
+    xd = to_ndhwc(x, dtype)
+    rd = to_ndhwc(res, dtype)
+    yd = torch.empty((n,) + osp + (cout,), dtype=dtype, device=DEV)
+    wd = w.to(DEV)
+    packed = ops.wpack(dtype, 2, wd, cin, cout, 3)
+    ops.convT3d_fwd(xd, yd, packed, wd, b.to(DEV), prelu_alpha=alpha.to(DEV), residual=rd)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(yd), ref) < tol(dtype)
 
 
 WGRAD_CASES = [
