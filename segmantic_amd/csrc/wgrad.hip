@@ -98,8 +98,8 @@ static inline bool wg_mfma_ok(int dtype, const segmi_act* x, const segmi_act* dy
 }
 static inline bool wg_small_ok(int dtype, const segmi_act* x, const segmi_act* dy, int ksize) {
   const int es = dtype_size(dtype);
-  return conv_small_ok(x->c, dy->c, ksize) && dy->ld % 4 == 0 &&
-         ((uintptr_t)dy->data % (4 * es)) == 0;
+  (void)es;
+  return conv_small_ok(x->c, dy->c, ksize) && aligned_rows(dy, dtype);
 }
 static inline int wg_direct_blocks(const segmi_act* dy) {
   const int64_t b = cdiv64(act_voxels(dy), 512);

@@ -244,7 +244,11 @@ WGRAD_CASES = [
     (32, 32, 3, 1, (4, 8, 8), 2),
     (64, 32, 3, 2, (8, 16, 16), 1),
     (32, 64, 3, 1, (5, 7, 9), 1),
-    (1, 16, 3, 2, (12, 12, 12), 2),   # direct
+    (1, 16, 3, 2, (12, 12, 12), 2),   # small-Cin MFMA kernel
+    (1, 16, 3, 2, (20, 36, 70), 1),   # small-Cin, many ragged tiles
+    (2, 16, 3, 1, (5, 9, 19), 2),     # small-Cin, stride 1
+    (4, 32, 3, 2, (8, 10, 34), 1),    # small-Cin, two output-channel tiles, 7 combo tiles
+    (3, 16, 3, 1, (4, 8, 16), 1),
     (128, 256, 1, 1, (4, 4, 4), 2),   # direct (k1)
     (16, 3, 3, 1, (6, 6, 6), 1),      # direct
 ]
