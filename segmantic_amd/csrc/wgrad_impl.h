@@ -34,18 +34,18 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) float lds_f32;
 
-template <typename T, int KS_, int S, int CT, int TD, int TH, int TW>
+template <typename T, int KS_, int S, int CTO, int CTI, int TD, int TH, int TW>
 struct WgradGeom {
   static constexpr int KS = KS_, PAD = (KS_ - 1) / 2, NTAPS = KS_ * KS_ * KS_;
   static constexpr int NTW = (NTAPS + 3) / 4;  // taps per wave
   static constexpr int NV = TD * TH * TW;
   static constexpr int NL = NV / 16;  // 16-voxel lines
   static constexpr int HD = (TD - 1) * S + KS, HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
-  static constexpr int ROWB = 16 * CT * (int)sizeof(T);
-  static constexpr int CPR = ROWB / 16;
-  static constexpr int YBYTES = NV * ROWB;
+  static constexpr int YROWB = 16 * CTO * (int)sizeof(T), XROWB = 16 * CTI * (int)sizeof(T);
+  static constexpr int YCPR = YROWB / 16, XCPR = XROWB / 16;
+  static constexpr int YBYTES = NV * YROWB;
   static constexpr int XROWS = HD * HH * HW;
-  static constexpr int LDS_BYTES = YBYTES + XROWS * ROWB;
+  static constexpr int LDS_BYTES = YBYTES + XROWS * XROWB;
   static constexpr int LPG = sizeof(T) == 2 ? 2 : 1;  // lines per mma16
   static_assert(NL % LPG == 0, "tile must hold whole k-steps");
   static_assert(TW == 8 || TW == 16, "tile width");
@@ -60,9 +60,9 @@ __device__ __forceinline__ constexpr int wg_line_row(int line) {
   return (z * S * HH + y * S) * HW;
 }
 
-template <typename T, int KS, int S, int CT, int TD, int TH, int TW>
+template <typename T, int KS, int S, int CTO, int CTI, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
-  using G = WgradGeom<T, KS, S, CT, TD, TH, TW>;
+  using G = WgradGeom<T, KS, S, CTO, CTI, TD, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ysm = smem;
   char* xsm = smem + G::YBYTES;
@@ -71,15 +71,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   const int g = lane >> 4, i16 = lane & 15;
 
   const int cochunk = blockIdx.y / p.ci_chunks, cichunk = blockIdx.y % p.ci_chunks;
-  const int co0 = cochunk * 16 * CT, ci0 = cichunk * 16 * CT;
+  const int co0 = cochunk * 16 * CTO, ci0 = cichunk * 16 * CTI;
 
-  f32x4 acc[G::NTW][CT][CT];
+  f32x4 acc[G::NTW][CTO][CTI];
 #pragma unroll
   for (int a = 0; a < G::NTW; ++a)
 #pragma unroll
-    for (int b = 0; b < CT; ++b)
+    for (int b = 0; b < CTO; ++b)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < CTI; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // wave-uniform tap offsets (bytes into the X tile)
   int tapoff[G::NTW];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     int tap = wave + 4 * ti;
     if (tap > G::NTAPS - 1) tap = G::NTAPS - 1;
     const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-    tapoff[ti] = ((kd * G::HH + kh) * G::HW + kw) * G::ROWB;
+    tapoff[ti] = ((kd * G::HH + kh) * G::HW + kw) * G::XROWB;
   }
 
   // per-lane address parts
@@ -96,18 +96,18 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   if constexpr (sizeof(T) == 2) {
     const int q = i16 >> 2, pp = i16 & 3;
     const int v = 4 * g + q;  // voxel within the line
-    ylane = v * G::ROWB + 8 * pp;
-    xlane = ((v / TW) * S * G::HW + (v % TW) * S) * G::ROWB + 8 * pp;
+    ylane = v * G::YROWB + 8 * pp;
+    xlane = ((v / TW) * S * G::HW + (v % TW) * S) * G::XROWB + 8 * pp;
   } else {
-    ylane = g * G::ROWB + 4 * i16;   // + 4u rows per sub-step
-    xlane = g * S * G::ROWB + 4 * i16;
+    ylane = g * G::YROWB + 4 * i16;   // + 4u rows per sub-step
+    xlane = g * S * G::XROWB + 4 * i16;
   }
 
   const char* xb = (const char*)p.x;
   const char* yb = (const char*)p.dy;
   // Register-staged software pipeline: the global loads of tile t+1 are issued before the MFMA
   // phase of tile t and land in LDS after it (global latency hides under compute).
-  constexpr int NLY = (G::NV * G::CPR + 255) / 256, NLX = (G::XROWS * G::CPR + 255) / 256;
+  constexpr int NLY = (G::NV * G::YCPR + 255) / 256, NLX = (G::XROWS * G::XCPR + 255) / 256;
   frag_t ry[NLY], rx[NLX];
   auto fetch = [&](int tile) {
     int t = tile;
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 #pragma unroll
     for (int k = 0; k < NLY; ++k) {        // dY tile [NV][16*CT]
       const int i = tid + 256 * k;
-      const int v = i / G::CPR, ch = i % G::CPR;
+      const int v = i / G::YCPR, ch = i % G::YCPR;
       const int z = oz0 + v / (TW * TH), y = oy0 + (v / TW) % TH, x = ox0 + v % TW;
       ry[k] = frag_t{0u, 0u, 0u, 0u};
-      if (i < G::NV * G::CPR && z < p.Dy && y < p.Hy && x < p.Wy) {
+      if (i < G::NV * G::YCPR && z < p.Dy && y < p.Hy && x < p.Wy) {
         const int64_t e = ((((int64_t)n * p.Dy + z) * p.Hy + y) * p.Wy + x) * p.ldy + co0;
         ry[k] = *reinterpret_cast<const frag_t*>(yb + e * (int64_t)sizeof(T) + ch * 16);
       }
@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {        // X halo tile [HD*HH*HW][16*CT]
       const int i = tid + 256 * k;
-      const int v = i / G::CPR, ch = i % G::CPR;
+      const int v = i / G::XCPR, ch = i % G::XCPR;
       const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
       const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
       rx[k] = frag_t{0u, 0u, 0u, 0u};
-      if (i < G::XROWS * G::CPR && (unsigned)z < (unsigned)p.Dx && (unsigned)y < (unsigned)p.Hx &&
+      if (i < G::XROWS * G::XCPR && (unsigned)z < (unsigned)p.Dx && (unsigned)y < (unsigned)p.Hx &&
           (unsigned)x < (unsigned)p.Wx) {
         const int64_t e = ((((int64_t)n * p.Dx + z) * p.Hx + y) * p.Wx + x) * p.ldx + ci0;
         rx[k] = *reinterpret_cast<const frag_t*>(xb + e * (int64_t)sizeof(T) + ch * 16);
@@ -146,14 +146,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 #pragma unroll
     for (int k = 0; k < NLY; ++k) {
       const int i = tid + 256 * k;
-      if (i < G::NV * G::CPR)
-        *reinterpret_cast<frag_t*>(ysm + (i / G::CPR) * G::ROWB + (i % G::CPR) * 16) = ry[k];
+      if (i < G::NV * G::YCPR)
+        *reinterpret_cast<frag_t*>(ysm + (i / G::YCPR) * G::YROWB + (i % G::YCPR) * 16) = ry[k];
     }
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {
       const int i = tid + 256 * k;
-      if (i < G::XROWS * G::CPR)
-        *reinterpret_cast<frag_t*>(xsm + (i / G::CPR) * G::ROWB + (i % G::CPR) * 16) = rx[k];
+      if (i < G::XROWS * G::XCPR)
+        *reinterpret_cast<frag_t*>(xsm + (i / G::XCPR) * G::XROWB + (i % G::XCPR) * 16) = rx[k];
     }
   };
   if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
@@ -165,34 +165,34 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 
 #pragma unroll
     for (int lg = 0; lg < G::NL / G::LPG; ++lg) {
-      frag_t af[CT];
+      frag_t af[CTO];
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CTO; ++ct) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4*)(ysm + ylane + (2 * lg) * 16 * G::ROWB + ct * 32));
+              (lds_s16x4*)(ysm + ylane + (2 * lg) * 16 * G::YROWB + ct * 32));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4*)(ysm + ylane + (2 * lg + 1) * 16 * G::ROWB + ct * 32));
+              (lds_s16x4*)(ysm + ylane + (2 * lg + 1) * 16 * G::YROWB + ct * 32));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           af[ct] = frag_t{l2[0], l2[1], h2[0], h2[1]};
         }
       } else {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CTO; ++ct) {
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            af[ct][u] = __float_as_uint(*(lds_f32*)(ysm + ylane + (lg * 16 + 4 * u) * G::ROWB + ct * 64));
+            af[ct][u] = __float_as_uint(*(lds_f32*)(ysm + ylane + (lg * 16 + 4 * u) * G::YROWB + ct * 64));
         }
       }
 #pragma unroll
       for (int ti = 0; ti < G::NTW; ++ti) {
         if (KS == 1 && wave != 0) break;  // k1: a single tap, owned by wave 0
-        frag_t bf[CT];
+        frag_t bf[CTI];
         if constexpr (sizeof(T) == 2) {
-          const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg) * G::ROWB;
-          const int r1 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg + 1) * G::ROWB;
+          const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg) * G::XROWB;
+          const int r1 = wg_line_row<S, TH, TW, G::HH, G::HW>(2 * lg + 1) * G::XROWB;
 #pragma unroll
-          for (int it = 0; it < CT; ++it) {
+          for (int it = 0; it < CTI; ++it) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (lds_s16x4*)(xsm + xlane + tapoff[ti] + r0 + it * 32));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -201,22 +201,22 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
             bf[it] = frag_t{l2[0], l2[1], h2[0], h2[1]};
           }
         } else {
-          const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(lg) * G::ROWB;
+          const int r0 = wg_line_row<S, TH, TW, G::HH, G::HW>(lg) * G::XROWB;
 #pragma unroll
-          for (int it = 0; it < CT; ++it) {
+          for (int it = 0; it < CTI; ++it) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               // voxel 4u+g of the line: TW=16 -> same x-row; TW=8 -> rows u>>1
               const int vo = TW == 16 ? 4 * u * S : ((u >> 1) * S * G::HW + 4 * (u & 1) * S);
               bf[it][u] = __float_as_uint(
-                  *(lds_f32*)(xsm + xlane + tapoff[ti] + r0 + vo * G::ROWB + it * 64));
+                  *(lds_f32*)(xsm + xlane + tapoff[ti] + r0 + vo * G::XROWB + it * 64));
             }
           }
         }
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CTO; ++ct)
 #pragma unroll
-          for (int it = 0; it < CT; ++it) acc[ti][ct][it] = mma16<T>(af[ct], bf[it], acc[ti][ct][it]);
+          for (int it = 0; it < CTI; ++it) acc[ti][ct][it] = mma16<T>(af[ct], bf[it], acc[ti][ct][it]);
       }
     }
   }
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     const int tap = wave + 4 * ti;
     if (tap < G::NTAPS) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CTO; ++ct)
 #pragma unroll
-        for (int it = 0; it < CT; ++it)
+        for (int it = 0; it < CTI; ++it)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int co = co0 + ct * 16 + 4 * g + e, ci = ci0 + it * 16 + i16;
@@ -240,17 +240,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   }
 }
 
-template <typename T, int KS, int S, int CT, int TD, int TH, int TW>
+template <typename T, int KS, int S, int CTO, int CTI, int TD, int TH, int TW>
 static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
-  using G = WgradGeom<T, KS, S, CT, TD, TH, TW>;
+  using G = WgradGeom<T, KS, S, CTO, CTI, TD, TH, TW>;
   p.tz = cdiv(p.Dy, TD);
   p.ty = cdiv(p.Hy, TH);
   p.tx = cdiv(p.Wy, TW);
   p.ntiles = p.N * p.tz * p.ty * p.tx;
-  p.ci_chunks = p.Cin / (16 * CT);
-  const int co_chunks = p.Cout / (16 * CT);
+  p.ci_chunks = p.Cin / (16 * CTI);
+  const int co_chunks = p.Cout / (16 * CTO);
   dim3 grid((unsigned)gx_hint, (unsigned)(co_chunks * p.ci_chunks));
-  auto kern = wgrad_mfma_kernel<T, KS, S, CT, TD, TH, TW>;
+  auto kern = wgrad_mfma_kernel<T, KS, S, CTO, CTI, TD, TH, TW>;
   static bool attr_done = false;
   if (!attr_done && G::LDS_BYTES > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -270,17 +270,39 @@ static inline int wgrad_tiles(const segmi_act* dy, int stride) {
   else { td = 2; th = wide ? 4 : 8; tw = wide ? 16 : 8; }
   return dy->n * cdiv(dy->d, td) * cdiv(dy->h, th) * cdiv(dy->w, tw);
 }
+// channel blocking of one workgroup, encoded 10*CTO + CTI (16-channel tiles of dY x of X).
+// bf16 only: 2x2 when both channel counts allow it; with 16 input channels (the wide layers,
+// where X is the big tensor) 2 output tiles share one staging of X (4x1 measured slower: 360
+// VGPRs).
 static inline int wgrad_ct(int dtype, int cin, int cout) {
-  return (dtype == SEGMI_BF16 && cin % 32 == 0 && cout % 32 == 0) ? 2 : 1;
+  if (dtype != SEGMI_BF16) return 11;
+  if (cin % 32 == 0 && cout % 32 == 0) return 22;
+  if (cin % 32 == 0) return 11;
+  if (cout % 32 == 0) return 21;
+  return 11;
 }
 static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int stride) {
   const int ct = wgrad_ct(dtype, x->c, dy->c);
-  const int chunks = (x->c / (16 * ct)) * (dy->c / (16 * ct));
-  int gx = 1024 / chunks;   // ~4 workgroups per CU: one stages while others compute
+  const int cto = ct / 10, cti = ct % 10;
+  const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
+  // workgroups wanted = a multiple of the 256 CUs; one per CU once the kernel holds > 1 channel
+  // tile (200-400 VGPRs, 55-110 KB slabs).  Measured on MI355X (scripts/wg_sweep.sh): 1x1 blocks
+  // 704/508/540/608 us at 256/512/1024/2048 workgroups, 2x2 blocks 125/198/348 us at 256/512/1024.
+  const int target = cto * cti == 1 ? 512 : 256;
+  int gx = target / chunks;
   if (gx < 1) gx = 1;
   const int nt = wgrad_tiles(dy, stride);
   return gx < nt ? gx : nt;
 }
+
+#define WG_CFG(KS, S, CTO, CTI)                                                         \
+  do {                                                                                   \
+    if (S == 1 || KS == 1)                                                               \
+      return wide ? launch_wgrad_cfg<T, KS, 1, CTO, CTI, 2, 8, 16>(p, gx, st)            \
+                  : launch_wgrad_cfg<T, KS, 1, CTO, CTI, 4, 8, 8>(p, gx, st);            \
+    return wide ? launch_wgrad_cfg<T, KS, S, CTO, CTI, 2, 4, 16>(p, gx, st)              \
+                : launch_wgrad_cfg<T, KS, S, CTO, CTI, 2, 8, 8>(p, gx, st);              \
+  } while (0)
 
 template <typename T>
 static int launch_wgrad_mfma_t(const WgradParams& p, int ksize, int stride, int ct, int gx,
@@ -288,24 +310,23 @@ static int launch_wgrad_mfma_t(const WgradParams& p, int ksize, int stride, int 
   const bool wide = p.Wy > 8;
   if (ksize == 1) {
     if constexpr (sizeof(T) == 2) {
-      if (ct == 2) return wide ? launch_wgrad_cfg<T, 1, 1, 2, 2, 8, 16>(p, gx, st)
-                               : launch_wgrad_cfg<T, 1, 1, 2, 4, 8, 8>(p, gx, st);
+      if (ct == 22) WG_CFG(1, 1, 2, 2);
+      if (ct == 21) WG_CFG(1, 1, 2, 1);
     }
-    return wide ? launch_wgrad_cfg<T, 1, 1, 1, 2, 8, 16>(p, gx, st)
-                : launch_wgrad_cfg<T, 1, 1, 1, 4, 8, 8>(p, gx, st);
+    WG_CFG(1, 1, 1, 1);
   }
   if constexpr (sizeof(T) == 2) {
-    if (ct == 2) {
-      if (stride == 1) return wide ? launch_wgrad_cfg<T, 3, 1, 2, 2, 8, 16>(p, gx, st)
-                                   : launch_wgrad_cfg<T, 3, 1, 2, 4, 8, 8>(p, gx, st);
-      return wide ? launch_wgrad_cfg<T, 3, 2, 2, 2, 4, 16>(p, gx, st)
-                  : launch_wgrad_cfg<T, 3, 2, 2, 2, 8, 8>(p, gx, st);
+    if (stride == 1) {
+      if (ct == 22) WG_CFG(3, 1, 2, 2);
+      if (ct == 21) WG_CFG(3, 1, 2, 1);
+    } else {
+      if (ct == 22) WG_CFG(3, 2, 2, 2);
+      if (ct == 21) WG_CFG(3, 2, 2, 1);
     }
   }
-  if (stride == 1) return wide ? launch_wgrad_cfg<T, 3, 1, 1, 2, 8, 16>(p, gx, st)
-                               : launch_wgrad_cfg<T, 3, 1, 1, 4, 8, 8>(p, gx, st);
-  return wide ? launch_wgrad_cfg<T, 3, 2, 1, 2, 4, 16>(p, gx, st)
-              : launch_wgrad_cfg<T, 3, 2, 1, 2, 8, 8>(p, gx, st);
+  if (stride == 1) WG_CFG(3, 1, 1, 1);
+  WG_CFG(3, 2, 1, 1);
 }
+#undef WG_CFG
 
 }  // namespace segmi

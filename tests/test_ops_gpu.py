@@ -244,6 +244,10 @@ WGRAD_CASES = [
     (32, 32, 3, 1, (4, 8, 8), 2),
     (64, 32, 3, 2, (8, 16, 16), 1),
     (32, 64, 3, 1, (5, 7, 9), 1),
+    (16, 64, 3, 2, (8, 8, 32), 1),    # bf16: 4 output tiles share one X staging
+    (16, 64, 3, 1, (4, 8, 16), 1),
+    (16, 32, 1, 1, (4, 8, 16), 2),    # k1, 2x1 blocking
+    (16, 96, 3, 1, (3, 5, 7), 1),     # 2x1 blocking with 3 output chunks, narrow tiles
     (1, 16, 3, 2, (12, 12, 12), 2),   # small-Cin MFMA kernel
     (1, 16, 3, 2, (20, 36, 70), 1),   # small-Cin, many ragged tiles
     (2, 16, 3, 1, (5, 9, 19), 2),     # small-Cin, stride 1
