@@ -192,6 +192,22 @@ int segmi_sw_scatter_add(int dtype, const segmi_act* pred, const int32_t* starts
  * label_bytes in {1,2,4}. */
 int segmi_sw_finalize(const segmi_act* acc, const float* cnt, int write_logits, void* labels,
                       int label_bytes, void* stream);
+/* Deferred form of the same blend (same reference call sites): the caller keeps EVERY window
+ * prediction of the dense schedule, `cache` = [win_hi - win_lo][rd][rh][rw][ldp >= k] of `dtype`
+ * (slot = window index - win_lo; window index = (iz*ny + iy)*nx + ix over the per-dimension origin
+ * lists, first dimension slowest -- MONAI's dense_patch_slices order).  One pass sums, per output
+ * voxel, the covering windows in ascending window index (the f32 addition order of the
+ * reference's sequential `out[slice] += w * pred`), then
+ *   normalize != 0: out_logits = sum / count (nullable), labels = argmax_k (nullable)
+ *   normalize == 0: out_logits = sum, out_count = count (partial result of a window shard).
+ * Origins are host arrays in un-padded image coordinates (may be negative); at most 64 per
+ * dimension (SEGMI_EUNSUPPORTED beyond: use the streaming segmi_sw_scatter_add).
+ * out_logits: f32 [d][h][w][ldo >= k]; out_count: f32 [d][h][w]; label_bytes in {1,2,4}. */
+int segmi_sw_blend(int dtype, const void* cache, int k, int ldp, const int32_t* starts_z, int nz,
+                   const int32_t* starts_y, int ny, const int32_t* starts_x, int nx, int win_lo,
+                   int win_hi, int rd, int rh, int rw, const float* importance, int d, int h, int w,
+                   float* out_logits, int ldo, float* out_count, void* labels, int label_bytes,
+                   int normalize, void* stream);
 /* AsDiscrete(argmax=True), monai_unet.py:129-134,622,673 */
 int segmi_argmax(int dtype, const segmi_act* logits, void* labels, int label_bytes,
                  void* stream);

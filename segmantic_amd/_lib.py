@@ -74,6 +74,8 @@ SIGNATURES = {
     "segmi_sw_gather": (_i, [_i, _AP, _i, _P, _i, _i, _AP, _P]),
     "segmi_sw_scatter_add": (_i, [_i, _AP, _P, _i, _P, _AP, _P, _P]),
     "segmi_sw_finalize": (_i, [_AP, _P, _i, _P, _i, _P]),
+    "segmi_sw_blend": (_i, [_i, _P, _i, _i, _P, _i, _P, _i, _P, _i, _i, _i, _i, _i, _i, _P, _i, _i, _i,
+                            _P, _i, _P, _P, _i, _i, _P]),
     "segmi_argmax": (_i, [_i, _AP, _P, _i, _P]),
     "segmi_label_counts": (_i, [_P, _P, _i64, _i, _P, _P]),
     "segmi_resample3d": (_i, [_i, _P, _i, _i, _i, _P, _i, _i, _i, _P, _i, _d, _P]),

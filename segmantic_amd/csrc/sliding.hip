@@ -174,6 +174,110 @@ __global__ void argmax_kernel(const T* __restrict__ lg, const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- deferred ordered blend
+// Every window prediction of the dense schedule is kept (`cache` slot = window index - lo); one
+// pass then sums, per output voxel, the covering windows in ascending window index -- the same
+// f32 addition sequence as the reference's sequential `out[slice] += w * pred` -- divides by the
+// count and takes the argmax.  Each prediction element is read exactly once and no f32
+// accumulator is read-modified-written per window group (5.4x less HBM traffic than the
+// streaming blend at overlap 0.5).
+constexpr int kMaxStarts = 64;
+struct BlendSched {
+  int n[3];
+  int start[3][kMaxStarts];   // per-dimension window origins, ascending (first dim slowest)
+};
+
+// G = channels per lane (16 bytes of T); K / G lanes cooperate on one voxel
+template <typename T, typename L, int G>
+__global__ __launch_bounds__(256) void sw_blend_kernel(
+    const T* __restrict__ cache, BlendSched sc, int lo, int hi, const float* __restrict__ imp,
+    float* __restrict__ out, float* __restrict__ cnt_out, L* __restrict__ labels, int D, int H,
+    int W, int K, int ldo, int rd, int rh, int rw, int ldp, int normalize) {
+  const int tpv = K / G;
+  const int64_t nvox = (int64_t)D * H * W;
+  const int64_t total = nvox * tpv;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e0 = blockIdx.x * 256ll; e0 < total; e0 += stride) {
+    const int64_t e = e0 + threadIdx.x;
+    const bool live = e < total;
+    const int64_t v = live ? e / tpv : 0;
+    const int k = (int)(e % tpv) * G;
+    int64_t t = v;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int z = (int)(t / H);
+    float a[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) a[j] = 0.f;
+    float c = 0.f;
+    if (live) {
+      for (int kz = 0; kz < sc.n[0]; ++kz) {
+        const int lz = z - sc.start[0][kz];
+        if ((unsigned)lz >= (unsigned)rd) continue;
+        for (int ky = 0; ky < sc.n[1]; ++ky) {
+          const int ly = y - sc.start[1][ky];
+          if ((unsigned)ly >= (unsigned)rh) continue;
+          for (int kx = 0; kx < sc.n[2]; ++kx) {
+            const int lx = x - sc.start[2][kx];
+            if ((unsigned)lx >= (unsigned)rw) continue;
+            const int w = (kz * sc.n[1] + ky) * sc.n[2] + kx;
+            if (w < lo || w >= hi) continue;
+            const int64_t lv = ((int64_t)lz * rh + ly) * rw + lx;
+            const float wt = imp ? imp[lv] : 1.f;
+            const T* pp = cache + ((int64_t)(w - lo) * rd * rh * rw + lv) * ldp + k;
+            if constexpr (G == 8) {
+              f32x4 p0, p1;
+              const u32x4 o = *reinterpret_cast<const u32x4*>(pp);
+              p0[0] = __uint_as_float(o[0] << 16); p0[1] = __uint_as_float(o[0] & 0xffff0000u);
+              p0[2] = __uint_as_float(o[1] << 16); p0[3] = __uint_as_float(o[1] & 0xffff0000u);
+              p1[0] = __uint_as_float(o[2] << 16); p1[1] = __uint_as_float(o[2] & 0xffff0000u);
+              p1[2] = __uint_as_float(o[3] << 16); p1[3] = __uint_as_float(o[3] & 0xffff0000u);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { a[j] += wt * p0[j]; a[4 + j] += wt * p1[j]; }
+            } else if constexpr (G == 4) {
+              const f32x4 p0 = load4<T>(pp);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a[j] += wt * p0[j];
+            } else {
+              a[0] += wt * Elem<T>::ld(pp);
+            }
+            c += wt;
+          }
+        }
+      }
+      if (normalize) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) a[j] = a[j] / c;
+      }
+      if (out) {
+        if constexpr (G >= 4) {
+#pragma unroll
+          for (int j = 0; j < G; j += 4)
+            *reinterpret_cast<f32x4*>(out + v * ldo + k + j) = f32x4{a[j], a[j + 1], a[j + 2], a[j + 3]};
+        } else {
+          out[v * ldo + k] = a[0];
+        }
+      }
+      if (cnt_out && k == 0) cnt_out[v] = c;
+    }
+    if (labels) {
+      float bv = a[0];
+      int bi = k;
+#pragma unroll
+      for (int j = 1; j < G; ++j)
+        if (am_better(bv, bi, a[j], k + j)) { bv = a[j]; bi = k + j; }
+      if (tpv <= 64 && (tpv & (tpv - 1)) == 0) {
+        for (int o = 1; o < tpv; o <<= 1) {
+          const float ov = __shfl_xor(bv, o);
+          const int oi = __shfl_xor(bi, o);
+          if (am_better(bv, bi, ov, oi)) { bv = ov; bi = oi; }
+        }
+        if (live && k == 0) labels[v] = (L)bi;
+      }
+    }
+  }
+}
+
 __global__ void label_counts_kernel(const int32_t* __restrict__ pred, const int32_t* __restrict__ truth,
                                     int64_t n, int K, unsigned long long* __restrict__ counts) {
   extern __shared__ unsigned int hist[];  // [K][3]
@@ -355,6 +459,76 @@ int segmi_argmax(int dtype, const segmi_act* logits, void* labels, int label_byt
   SEGMI_CHECK_ARG(act_ok(logits) && labels, "argmax: bad arguments");
   SEGMI_CHECK_ARG(label_bytes == 1 || label_bytes == 2 || label_bytes == 4, "argmax: label_bytes");
   return argmax_launch(dtype, logits, nullptr, 0, labels, label_bytes, (hipStream_t)stream);
+}
+
+int segmi_sw_blend(int dtype, const void* cache, int k, int ldp, const int32_t* starts_z, int nz,
+                   const int32_t* starts_y, int ny, const int32_t* starts_x, int nx, int win_lo,
+                   int win_hi, int rd, int rh, int rw, const float* importance, int d, int h, int w,
+                   float* out_logits, int ldo, float* out_count, void* labels, int label_bytes,
+                   int normalize, void* stream) {
+  SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "sw_blend: bad dtype");
+  SEGMI_CHECK_ARG(cache && starts_z && starts_y && starts_x && k > 0 && ldp >= k && rd > 0 &&
+                      rh > 0 && rw > 0 && d > 0 && h > 0 && w > 0,
+                  "sw_blend: bad arguments");
+  SEGMI_CHECK_ARG(out_logits || labels, "sw_blend: nothing to write");
+  SEGMI_CHECK_ARG(!out_logits || ldo >= k, "sw_blend: bad logits row stride");
+  if (nz > kMaxStarts || ny > kMaxStarts || nx > kMaxStarts || nz < 1 || ny < 1 || nx < 1)
+    SEGMI_UNSUPPORTED("sw_blend: at most %d window origins per dimension", kMaxStarts);
+  SEGMI_CHECK_ARG(0 <= win_lo && win_lo < win_hi && (int64_t)win_hi <= (int64_t)nz * ny * nx,
+                  "sw_blend: window range [%d, %d) outside the schedule", win_lo, win_hi);
+  SEGMI_CHECK_ARG(!labels || normalize, "sw_blend: labels need the normalised blend");
+  SEGMI_CHECK_ARG(!labels || label_bytes == 1 || label_bytes == 2 || label_bytes == 4,
+                  "sw_blend: label_bytes");
+  SEGMI_CHECK_ARG(!labels || label_bytes > 1 || k <= 256, "sw_blend: uint8 labels hold at most 256 classes");
+  BlendSched sc{};
+  sc.n[0] = nz; sc.n[1] = ny; sc.n[2] = nx;
+  for (int i = 0; i < nz; ++i) sc.start[0][i] = starts_z[i];
+  for (int i = 0; i < ny; ++i) sc.start[1][i] = starts_y[i];
+  for (int i = 0; i < nx; ++i) sc.start[2][i] = starts_x[i];
+  const int es = dtype_size(dtype);
+  const int gfull = 16 / es;
+  const bool vec = k % gfull == 0 && ldp % gfull == 0 && ((uintptr_t)cache % 16) == 0 &&
+                   (!out_logits || (ldo % 4 == 0 && ((uintptr_t)out_logits % 16) == 0)) &&
+                   (k / gfull) <= 64 && ((k / gfull) & (k / gfull - 1)) == 0;
+  SEGMI_CHECK_ARG(vec || !labels || k <= 64,
+                  "sw_blend: the scalar path (K %% %d != 0) labels at most 64 classes", gfull);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nvox = (int64_t)d * h * w;
+  const int64_t lanes = nvox * (vec ? k / gfull : k);
+  const int grid = grid_for(lanes);
+#define BLEND(TT, LL, GG)                                                                         \
+  hipLaunchKernelGGL((sw_blend_kernel<TT, LL, GG>), grid, 256, 0, st, (const TT*)cache, sc, win_lo, \
+                     win_hi, importance, out_logits, out_count, (LL*)labels, d, h, w, k, ldo, rd, \
+                     rh, rw, ldp, normalize)
+  if (vec) {
+    if (dtype == SEGMI_BF16) {
+      if (label_bytes == 1) BLEND(bf16_t, uint8_t, 8);
+      else if (label_bytes == 2) BLEND(bf16_t, uint16_t, 8);
+      else BLEND(bf16_t, int32_t, 8);
+    } else {
+      if (label_bytes == 1) BLEND(float, uint8_t, 4);
+      else if (label_bytes == 2) BLEND(float, uint16_t, 4);
+      else BLEND(float, int32_t, 4);
+    }
+  } else {
+    // scalar lanes: one channel each; labels (if wanted) come from a second pass over the logits
+    SEGMI_CHECK_ARG(!labels || out_logits, "sw_blend: the scalar path labels from the written logits");
+    if (dtype == SEGMI_BF16) hipLaunchKernelGGL((sw_blend_kernel<bf16_t, int32_t, 1>), grid, 256, 0, st,
+        (const bf16_t*)cache, sc, win_lo, win_hi, importance, out_logits, out_count, (int32_t*)nullptr,
+        d, h, w, k, ldo, rd, rh, rw, ldp, normalize);
+    else hipLaunchKernelGGL((sw_blend_kernel<float, int32_t, 1>), grid, 256, 0, st,
+        (const float*)cache, sc, win_lo, win_hi, importance, out_logits, out_count, (int32_t*)nullptr,
+        d, h, w, k, ldo, rd, rh, rw, ldp, normalize);
+    SEGMI_LAUNCH_CHECK("sw_blend");
+    if (labels) {
+      segmi_act lg{out_logits, 1, d, h, w, k, ldo};
+      return argmax_launch(SEGMI_F32, &lg, nullptr, 0, labels, label_bytes, st);
+    }
+    return SEGMI_OK;
+  }
+#undef BLEND
+  SEGMI_LAUNCH_CHECK("sw_blend");
+  return SEGMI_OK;
 }
 
 int segmi_label_counts(const int32_t* pred, const int32_t* truth, int64_t n, int k,

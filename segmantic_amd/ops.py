@@ -328,6 +328,27 @@ def sw_finalize(acc, cnt, labels, write_logits=True) -> None:
                                 _LABEL_BYTES[labels.dtype], _stream()), "sw_finalize")
 
 
+def sw_blend(cache, starts_zyx, win_lo, win_hi, roi, d, h, w, importance=None, out_logits=None,
+             out_count=None, labels=None, normalize=True) -> None:
+    """cache [slots, rd, rh, rw, K] (NDHWC, bf16/f32); starts_zyx = three ascending origin lists."""
+    _require_device(cache)
+    if cache.dim() != 5 or cache.stride(4) != 1 or not cache.is_contiguous():
+        raise ValueError("sw_blend: cache must be a contiguous [slots, rd, rh, rw, K] tensor")
+    arrs = [np.ascontiguousarray(np.asarray(sv, dtype=np.int32)) for sv in starts_zyx]
+    k = cache.shape[4]
+    ldo = out_logits.stride(-2) if out_logits is not None else 0
+    if out_logits is not None and (out_logits.dtype != torch.float32 or out_logits.stride(-1) != 1):
+        raise ValueError("sw_blend: out_logits must be float32 NDHWC")
+    check(lib.segmi_sw_blend(
+        dtype_code(cache), _ptr(cache), k, cache.stride(3),
+        arrs[0].ctypes.data_as(C.c_void_p), len(arrs[0]), arrs[1].ctypes.data_as(C.c_void_p),
+        len(arrs[1]), arrs[2].ctypes.data_as(C.c_void_p), len(arrs[2]), int(win_lo), int(win_hi),
+        int(roi[0]), int(roi[1]), int(roi[2]), _ptr(importance), int(d), int(h), int(w),
+        _ptr(out_logits), int(ldo), _ptr(out_count), _ptr(labels),
+        _LABEL_BYTES[labels.dtype] if labels is not None else 1, int(bool(normalize)), _stream()),
+        "sw_blend")
+
+
 def argmax(logits, labels) -> None:
     a = act(logits)
     check(lib.segmi_argmax(dtype_code(logits), C.byref(a), _ptr(labels),

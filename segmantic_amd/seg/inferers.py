@@ -9,9 +9,11 @@ Window schedule (host, integer arithmetic -- identical to MONAI's ``dense_patch_
   interval = roi if roi == img else max(int(roi * (1 - overlap)), 1);
   n = ceil((img - roi) / interval) + 1 ; start_k = min(k * interval, img - roi);
   windows enumerated with the first spatial dim slowest, groups of ``sw_batch_size``.
-Data path (device): gather kernel -> predictor -> ordered blend kernel into an f32 NDHWC
-accumulator + count map -> divide (+ fused argmax).  The blend adds windows in schedule order so
-its f32 result is bit-identical to the reference's sequential ``out[slice] += w * pred``.
+Data path (device): gather kernel -> predictor -> ordered blend -> divide (+ fused argmax).  The
+blend adds the windows covering a voxel in schedule order in f32, so its result is bit-identical
+to the reference's sequential ``out[slice] += w * pred``; it runs either deferred (all window
+predictions kept in HBM, one blend pass, ``segmi_sw_blend``) or streaming (f32 accumulator
+read-modify-written per window group, ``segmi_sw_scatter_add``).
 """
 from __future__ import annotations
 
@@ -35,14 +37,19 @@ def scan_intervals(image_size, roi, overlap) -> List[int]:
     return out
 
 
-def window_starts(image_size, roi, overlap) -> List[Tuple[int, ...]]:
+def dense_starts(image_size, roi, overlap) -> List[List[int]]:
+    """Per-dimension window origins (ascending) of MONAI's dense schedule."""
     iv = scan_intervals(image_size, roi, overlap)
     per_dim = []
     for i, r, s in zip(image_size, roi, iv):
         n = int(math.ceil(float(i - r) / s)) + 1
         per_dim.append([min(k * s, i - r) for k in range(n)])
+    return per_dim
+
+
+def window_starts(image_size, roi, overlap) -> List[Tuple[int, ...]]:
     wins = [()]
-    for starts in per_dim:
+    for starts in dense_starts(image_size, roi, overlap):
         wins = [w + (s,) for w in wins for s in starts]
     return wins
 
@@ -67,16 +74,29 @@ class SlidingWindowResult:
         self.logits, self.labels, self.count = logits, labels, count
 
 
+def _cache_budget_bytes(device) -> int:
+    free, _total = torch.cuda.mem_get_info(device)
+    return int(free * 0.6)
+
+
 def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_batch_size: int,
                              predictor: Callable[[torch.Tensor], torch.Tensor],
                              overlap: float = 0.25, mode: str = "constant",
                              sigma_scale: float = 0.125, device=None,
                              return_labels: bool = False, window_dtype: torch.dtype = torch.float32,
-                             window_range: Optional[Tuple[int, int]] = None):
+                             window_range: Optional[Tuple[int, int]] = None,
+                             blend: str = "auto", return_logits: bool = True):
     """inputs [B,C,D,H,W] float32 on the GPU.  ``predictor`` maps [b,C,*roi] -> [b,K,*roi].
 
-    Returns logits [B,K,D,H,W] (float32), or a ``SlidingWindowResult`` when ``return_labels``.
-    ``window_range`` restricts the schedule to windows [lo, hi) (multi-GPU sharding).
+    Returns logits [B,K,D,H,W] (float32), or a ``SlidingWindowResult`` when ``return_labels``
+    (``return_logits=False`` then skips the f32 logits volume).  ``window_range`` restricts the
+    schedule to windows [lo, hi) (multi-GPU sharding; the result is then the un-normalised sum).
+
+    ``blend``: "deferred" keeps every window prediction in HBM (5.4x the logits volume at overlap
+    0.5, in the predictor's dtype) and blends once -- each prediction is read exactly once;
+    "stream" read-modify-writes an f32 accumulator per window group (the reference's data flow);
+    "auto" picks deferred when the cache fits in 60 % of the free HBM.  Both add the windows of a
+    voxel in schedule order in f32, so their results are bit-identical.
     """
     if inputs.dim() != 5:
         raise ValueError("sliding_window_inference expects [B,C,D,H,W]")
@@ -84,15 +104,21 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         raise RuntimeError("segmantic_amd sliding-window inference runs on the GPU only")
     if not 0 <= overlap < 1:
         raise ValueError("overlap must be >= 0 and < 1.")
+    if blend not in ("auto", "deferred", "stream"):
+        raise ValueError(f"unsupported blend strategy {blend}")
     B, Cin = inputs.shape[0], inputs.shape[1]
     orig = list(inputs.shape[2:])
     roi = [int(r) if r else int(o) for r, o in zip(roi_size, orig)]
     image_size = [max(o, r) for o, r in zip(orig, roi)]
     pad_lo = [max(r - o, 0) // 2 for o, r in zip(orig, roi)]
-    wins = window_starts(image_size, roi, overlap)
+    per_dim = dense_starts(image_size, roi, overlap)
+    wins = [()]
+    for starts in per_dim:
+        wins = [w + (s,) for w in wins for s in starts]
     lo, hi = (0, len(wins)) if window_range is None else window_range
     # window origins in un-padded image coordinates (the gather kernel zero-fills outside)
     wins_u = [tuple(s - p for s, p in zip(w, pad_lo)) for w in wins]
+    per_dim_u = [[s - p for s in lst] for lst, p in zip(per_dim, pad_lo)]
     img = inputs.float()
     img = img.view(B, orig[0], orig[1], orig[2], 1) if Cin == 1 and img.is_contiguous() else as_ndhwc(img)
     imp = None
@@ -100,34 +126,63 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         imp = gaussian_importance(roi, sigma_scale, inputs.device).view(-1)
     elif mode != "constant":
         raise ValueError(f"unsupported blend mode {mode}")
-    acc = None
-    cnt = None
-    K = None
+    dev = inputs.device
+    into = getattr(getattr(predictor, "__self__", predictor), "forward_into", None)
+    partial = window_range is not None
+    want_logits = return_logits or not return_labels or partial
+    nvox_roi = roi[0] * roi[1] * roi[2]
     outs, labs, cnts = [], [], []
     for b in range(B):
+        acc = cnt = cache = None
+        K = None
+        deferred = False
         for g0 in range(lo, hi, sw_batch_size):
             grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
             wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
-                               device=inputs.device)
+                               device=dev)
             ops.sw_gather(img, b, grp, wbuf)
-            pred = predictor(wbuf.permute(0, 4, 1, 2, 3))
-            pn = as_ndhwc(pred)
-            if acc is None:
+            wview = wbuf.permute(0, 4, 1, 2, 3)
+            slot = g0 - lo
+            if cache is not None and into is not None and into(wview, cache[slot:slot + len(grp)]):
+                continue                                   # predicted straight into the cache
+            pn = as_ndhwc(predictor(wview))
+            if K is None:                                  # first group: pick the strategy
                 K = pn.shape[4]
-                acc = torch.zeros((1, orig[0], orig[1], orig[2], K), dtype=torch.float32,
-                                  device=inputs.device)
-                cnt = torch.zeros((orig[0], orig[1], orig[2]), dtype=torch.float32,
-                                  device=inputs.device)
-            ops.sw_scatter_add(pn, grp, acc, cnt, imp)
-        if window_range is not None:
-            outs.append(acc); cnts.append(cnt); labs.append(None)
-        else:
+                need = (hi - lo) * nvox_roi * K * pn.element_size()
+                deferred = blend != "stream" and max(len(v) for v in per_dim) <= 64 and (
+                    blend == "deferred" or need <= _cache_budget_bytes(dev))
+                if deferred:
+                    cache = torch.empty((hi - lo, roi[0], roi[1], roi[2], K), dtype=pn.dtype,
+                                        device=dev)
+                else:
+                    acc = torch.zeros((1, orig[0], orig[1], orig[2], K), dtype=torch.float32,
+                                      device=dev)
+                    cnt = torch.zeros((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
+            if deferred:
+                cache[slot:slot + len(grp)].copy_(pn)
+            else:
+                ops.sw_scatter_add(pn, grp, acc, cnt, imp)
+        lab = None
+        if not partial and return_labels:
             lab = torch.empty((orig[0], orig[1], orig[2]),
-                              dtype=torch.uint8 if K <= 256 else torch.int32, device=inputs.device)
+                              dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)
+        if deferred:
+            if want_logits:
+                acc = torch.empty((1, orig[0], orig[1], orig[2], K), dtype=torch.float32, device=dev)
+            cnt = torch.empty((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
+            ops.sw_blend(cache, per_dim_u, lo, hi, roi, orig[0], orig[1], orig[2], importance=imp,
+                         out_logits=acc if want_logits else None, out_count=cnt, labels=lab,
+                         normalize=not partial)
+            cache = None
+        elif not partial:
+            if lab is None:
+                lab = torch.empty((orig[0], orig[1], orig[2]),
+                                  dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)
             ops.sw_finalize(acc, cnt, lab, write_logits=True)
-            outs.append(acc); cnts.append(cnt); labs.append(lab)
-        acc = cnt = None
-    logits = torch.cat(outs, 0).permute(0, 4, 1, 2, 3) if B > 1 else outs[0].permute(0, 4, 1, 2, 3)
+        outs.append(acc); cnts.append(cnt); labs.append(lab if return_labels and not partial else None)
+    logits = None
+    if outs[0] is not None:
+        logits = (torch.cat(outs, 0) if B > 1 else outs[0]).permute(0, 4, 1, 2, 3)
     if not return_labels:
         return logits
     labels = None if labs[0] is None else torch.stack(labs).unsqueeze(1)

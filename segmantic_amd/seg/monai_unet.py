@@ -158,6 +158,17 @@ class Net(torch.nn.Module):
                 return _UNetFn.apply(x, self._anchor, self)
             return eng.forward(x, train=self.training).permute(0, 4, 1, 2, 3)
 
+    def forward_into(self, x: torch.Tensor, out_ndhwc: torch.Tensor) -> bool:
+        """Inference forward straight into a caller-owned NDHWC [B, D, H, W, K] buffer of the
+        compute dtype (the sliding-window prediction cache).  Returns False when the module is in
+        training mode or the buffer does not fit, so the caller falls back to ``forward``."""
+        eng = self._engine_for(x)
+        if self.training or out_ndhwc.dtype != eng.dtype or not out_ndhwc.is_contiguous():
+            return False
+        with torch.cuda.device(eng.device):
+            eng.forward(x, train=False, out=out_ndhwc)
+        return True
+
     # ------------------------------------------------------------------ optimisers
     def configure_optimizers(self):
         eng = self._engine_for()

@@ -693,12 +693,25 @@ class UNetEngine:
         ops.nchw_to_ndhwc(x.float().contiguous(), xin)
         return xin
 
-    def forward(self, x: torch.Tensor, train: Optional[bool] = None) -> torch.Tensor:
-        """[N,C,D,H,W] f32 -> logits NDHWC tensor [N,D,H,W,K] (compute dtype)."""
+    def forward(self, x: torch.Tensor, train: Optional[bool] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[N,C,D,H,W] f32 -> logits NDHWC tensor [N,D,H,W,K] (compute dtype).
+
+        ``out`` (eval mode): caller-owned dense NDHWC destination of the compute dtype, e.g. a
+        slot range of the sliding-window prediction cache; otherwise an engine buffer that the
+        next call overwrites."""
         train = self.training if train is None else train
         xin = self._prep_input(x)
         n, d, h, w, _ = xin.shape
-        logits = self._buf("logits." + ("t" if train else "e"), (n, d, h, w, self.net.out_channels))
+        shape = (n, d, h, w, self.net.out_channels)
+        if out is not None:
+            if train:
+                raise ValueError("forward(out=...) is an inference-only path")
+            if tuple(out.shape) != shape or out.dtype != self.dtype or not out.is_contiguous():
+                raise ValueError(f"out must be a contiguous {shape} {self.dtype} tensor")
+            logits = out
+        else:
+            logits = self._buf("logits." + ("t" if train else "e"), shape)
         if train:
             self._saved.clear()
             self._nbt_flat += 1        # every BatchNorm runs exactly once per training forward

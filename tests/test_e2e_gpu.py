@@ -89,6 +89,29 @@ def test_sliding_window_through_the_network_vs_oracle(overlap, mode):
     assert torch.equal(res.labels.cpu().long()[:, 0], torch.argmax(got, 1))
 
 
+@pytest.mark.parametrize("mode", ["constant", "gaussian"])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_sliding_window_deferred_and_streaming_blends_are_bit_identical(mode, mixed):
+    """Same windows, same f32 addition order: keeping all predictions and blending once gives
+    the very bits the per-group accumulator gives (logits, counts and labels)."""
+    _, net = pair(16, (16, 32, 64), (2, 2))
+    net.eval()
+    net.mixed_precision = mixed
+    img, _ = synthetic_batch(1, 40, 4, seed=5)
+    img = img[..., :40, :36, :44].to(DEV)
+    with torch.no_grad():
+        a = sliding_window_inference(img, (16, 16, 16), 4, net, 0.5, mode, return_labels=True,
+                                     blend="stream")
+        la, ca, ba = a.logits.clone(), a.count.clone(), a.labels.clone()
+        b = sliding_window_inference(img, (16, 16, 16), 4, net, 0.5, mode, return_labels=True,
+                                     blend="deferred")
+        c = sliding_window_inference(img, (16, 16, 16), 4, net, 0.5, mode, return_labels=True,
+                                     blend="deferred", return_logits=False)
+    torch.cuda.synchronize()
+    assert torch.equal(la, b.logits) and torch.equal(ca, b.count) and torch.equal(ba, b.labels)
+    assert c.logits is None and torch.equal(c.labels, ba)
+
+
 def test_sliding_window_image_smaller_than_roi_and_inferer_class():
     ref, net = pair(2, (16, 32), (2,))
     ref.eval(); net.eval()

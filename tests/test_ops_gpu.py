@@ -442,6 +442,60 @@ def test_sliding_window_ops_match_oracle():
         assert torch.equal(lab.cpu().long(), torch.argmax(ref, 1)[0])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K", [4, 16, 3])
+def test_sliding_window_deferred_blend_matches_oracle(K, dtype):
+    """segmi_sw_blend: every window kept, one ordered blend pass == the sequential reference
+    (bit-exact in f32), including the argmax and a two-shard partial blend."""
+    from oracle.sliding_ref import ref_sliding_window_inference
+    from segmantic_amd.seg.inferers import dense_starts
+    img = rnd((1, 1, 20, 27, 33), 93)
+    roi = (16, 16, 16)
+    wts = rnd((K, 1, 3, 3, 3), 94)
+
+    def predictor(x):   # window predictions rounded to the cache dtype, as the network emits them
+        return q(F.conv3d(x, wts, padding=1), dtype)
+
+    for overlap in (0.25, 0.5):
+        ref, cnt_ref, wins = ref_sliding_window_inference(img, roi, 4, predictor, overlap)
+        per_dim = dense_starts((20, 27, 33), roi, overlap)
+        cache = torch.empty((len(wins),) + roi + (K,), dtype=dtype, device=DEV)
+        for g0 in range(0, len(wins), 4):   # same window batches as the oracle (CPU conv kernels
+            grp = wins[g0:g0 + 4]           # may round differently for another batch size)
+            pred = predictor(torch.cat([img[:, :, z:z + 16, y:y + 16, x:x + 16] for z, y, x in grp]))
+            cache[g0:g0 + len(grp)] = pred.permute(0, 2, 3, 4, 1).to(DEV).to(dtype)
+        out = torch.empty((1, 20, 27, 33, K), device=DEV)
+        cnt = torch.empty((20, 27, 33), device=DEV)
+        lab = torch.empty((20, 27, 33), dtype=torch.uint8, device=DEV)
+        ops.sw_blend(cache, per_dim, 0, len(wins), roi, 20, 27, 33, out_logits=out, out_count=cnt, labels=lab)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt.cpu(), cnt_ref[0, 0])
+        got = out.cpu().permute(0, 4, 1, 2, 3)
+        assert torch.equal(got, ref)
+        assert torch.equal(lab.cpu().long(), torch.argmax(ref, 1)[0])
+        # labels only (no f32 logits volume)
+        lab2 = torch.empty_like(lab)
+        if K % (8 if dtype == torch.bfloat16 else 4) == 0:
+            ops.sw_blend(cache, per_dim, 0, len(wins), roi, 20, 27, 33, labels=lab2)
+            torch.cuda.synchronize()
+            assert torch.equal(lab2, lab)
+        # two window shards, un-normalised partial sums: their sum / count reproduces the blend
+        # up to the association of the f32 additions across the shard boundary
+        mid = len(wins) // 2
+        parts = []
+        for lo, hi in ((0, mid), (mid, len(wins))):
+            a = torch.empty((1, 20, 27, 33, K), device=DEV)
+            c = torch.empty((20, 27, 33), device=DEV)
+            ops.sw_blend(cache[lo:hi].contiguous(), per_dim, lo, hi, roi, 20, 27, 33, out_logits=a,
+                         out_count=c, normalize=False)
+            parts.append((a, c))
+        torch.cuda.synchronize()
+        csum = parts[0][1] + parts[1][1]
+        assert torch.equal(csum.cpu(), cnt_ref[0, 0])
+        tot = ((parts[0][0] + parts[1][0]) / csum[None, ..., None]).cpu().permute(0, 4, 1, 2, 3)
+        assert float((tot - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def test_label_counts_and_dice_metric():
     from oracle.metrics_ref import ref_dice_metric
     g = torch.Generator().manual_seed(95)
