@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
   for (int j = 0; j < NT; ++j) { ssum[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.res;
+  // identity residual (out = conv(x) + x, the top unit of the decoder and its dgrad): the rows are
+  // the centre plane of the ring, already in LDS -- no second HBM read of x
+  const bool res_in = resp && p.res == p.in && p.ldr == p.ldi && p.Cin == p.Cout;
 
   for (int step = 0; step < nsteps_z; ++step) {
     const int zb = step * G::TD;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
     // ---- prefetch the residual rows of this step's outputs
     const int oz = z0 + zb + wave;
     typename Raw4<T>::type resv[8][NT];   // kept in storage format (2 VGPRs per bf16 row)
-    if (resp) {
+    if (resp && !res_in) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int oy = oy0 + i, ox = ox0 + r;
@@ -243,6 +246,15 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
         const int slot = (zb + 6 + s_pl[k]) % G::R;
         *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + s_loff[k]) = stg[k];
       }
+    }
+    if (res_in) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          resv[i][j] = *reinterpret_cast<const typename Raw4<T>::type*>(
+              smem + pofs[1] + ((i + 1) * G::HW + r + 1) * G::ROWB +
+              ((nt0 + j) * 16 + 4 * g) * (int)sizeof(T));
     }
     // ---- epilogue of this step
 #pragma unroll

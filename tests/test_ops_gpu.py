@@ -138,6 +138,27 @@ def test_conv3d_ring_kernel_epilogue(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,sp", [(16, (16, 64, 128)), (32, (20, 30, 70))])
+def test_conv3d_ring_kernel_identity_residual(dtype, c, sp):
+    """out = conv(x) + x with residual == input view: the ring kernel takes the residual rows
+    from its LDS planes; must equal the separately-loaded residual bit for bit."""
+    n = 2
+    x = rnd((n, c) + sp, 19)
+    w, b = rnd((c, c, 3, 3, 3), 20, 0.05), rnd((c,), 21, 0.1)
+    ref = F.conv3d(q(x, dtype), q(w, dtype), b, padding=1) + q(x, dtype)
+    xd = to_ndhwc(x, dtype)
+    x2 = xd.clone()
+    y1, y2 = torch.empty_like(xd), torch.empty_like(xd)
+    wd = w.to(DEV)
+    packed = ops.wpack(dtype, 0, wd, c, c, 3)
+    ops.conv3d_fwd(xd, y1, packed, None, 0, b.to(DEV), 3, 1, residual=xd)    # LDS residual
+    ops.conv3d_fwd(xd, y2, packed, None, 0, b.to(DEV), 3, 1, residual=x2)    # HBM residual
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert relerr(from_ndhwc(y1), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(16, 16, (6, 8, 20), 2), (32, 16, (4, 6, 8), 1), (4, 8, (5, 5, 5), 1)])
 def test_conv3d_dgrad_s1(case, dtype):
     """stride-1 dgrad = conv with flipped / transposed weights (pack kind 1)."""
