@@ -3,6 +3,7 @@
 // tiny test networks).
 #include "conv_fwd_impl.h"
 #include "conv_ring_impl.h"
+#include "conv_ks_impl.h"
 #include "convt_ps_impl.h"
 
 namespace segmi {
@@ -134,6 +135,7 @@ int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out
   if (mfma_ok(in->c, out->c)) {
     if (conv_ring_ok(dtype, in->c, ksize, stride, out))
       return conv_ring_rows(dtype, in->c, out) + stats_reserve_rows();
+    if (conv_ks_ok(dtype, in->c, ksize, stride)) return conv_ks_rows(out) + stats_reserve_rows();
     return conv_mfma_rows(out, stride) + stats_reserve_rows();
   }
   return bn_stats_rows_for(out) + stats_reserve_rows();
