@@ -56,6 +56,9 @@ CONV_CASES = [
     (16, 16, 3, 1, (16, 64, 128), 4),    # z-marching ring kernel, 256 columns, 1 segment
     (16, 16, 3, 1, (33, 60, 120), 2),    # ring kernel, 2 z-segments, ragged extents
     (32, 32, 3, 1, (33, 60, 120), 2),    # ring kernel, CK=32, two output tiles
+    (128, 48, 3, 1, (5, 6, 7), 2),       # k-split kernel, odd tile count, narrow + ragged tiles
+    (64, 64, 3, 1, (9, 10, 40), 2),      # k-split kernel, wide tiles, two output tiles per workgroup
+    (256, 32, 3, 1, (8, 8, 8), 1),       # k-split kernel, 8 bf16 / 16 f32 chunks
     (1, 16, 3, 2, (12, 12, 12), 2),   # direct kernel (first layer)
     (16, 3, 3, 1, (6, 7, 9), 1),      # direct kernel (K=3 head)
     (4, 8, 3, 2, (9, 9, 9), 1),       # direct kernel, odd extents
@@ -135,6 +138,34 @@ def test_conv3d_ring_kernel_epilogue(dtype):
     ssum = stats[:, 0].double().sum(0).cpu()
     assert float((ssum - raw.double().sum((0, 2, 3, 4))).abs().max()) / (raw.numel() / c) < \
         (1e-5 if dtype == torch.float32 else 2e-2) * float(raw.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_ksplit_kernel_epilogue(dtype):
+    """k-split kernel (deep layers): PReLU + residual + fused statistics, channel-slice views"""
+    n, cin, cout, sp = 2, 128, 64, (6, 9, 11)
+    x, r = rnd((n, cin) + sp, 35), rnd((n, cout) + sp, 36)
+    w, b = rnd((cout, cin, 3, 3, 3), 37, 0.02), rnd((cout,), 38, 0.1)
+    raw = F.conv3d(q(x, dtype), q(w, dtype), b, padding=1)
+    ref = F.prelu(raw, torch.tensor([0.3])) + q(r, dtype)
+    big_in = torch.zeros((n,) + sp + (192,), dtype=dtype, device=DEV)
+    big_in[..., 64:192] = to_ndhwc(x, dtype)
+    yd = torch.empty((n,) + sp + (cout,), dtype=dtype, device=DEV)
+    rd = to_ndhwc(r, dtype)
+    wd = w.to(DEV)
+    packed = ops.wpack(dtype, 0, wd, cin, cout, 3)
+    rows = ops.conv3d_stats_rows(big_in[..., 64:192], yd, 3, 1)
+    stats = torch.zeros((rows, 2, cout), device=DEV)
+    ops.conv3d_fwd(big_in[..., 64:192], yd, packed, None, 0, b.to(DEV), 3, 1,
+                   prelu_alpha=torch.tensor([0.3], device=DEV), residual=rd, stats=stats)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(yd), ref) < tol(dtype)
+    ssum = stats[:, 0].double().sum(0).cpu()
+    assert float((ssum - raw.double().sum((0, 2, 3, 4))).abs().max()) / (raw.numel() / cout) < \
+        (1e-5 if dtype == torch.float32 else 2e-2) * float(raw.abs().max())
+    ssq = stats[:, 1].double().sum(0).cpu()
+    assert float(((ssq - (raw.double() ** 2).sum((0, 2, 3, 4))).abs() / (raw.double() ** 2).sum((0, 2, 3, 4))).max()) < \
+        (1e-5 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
