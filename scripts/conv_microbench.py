@@ -8,6 +8,7 @@ shapes = [  # (N, Cin, Cout, D, stride)
     (8, 64, 64, 32, 1), (8, 32, 64, 64, 2), (8, 128, 128, 16, 1), (8, 64, 128, 32, 2),
     (8, 128, 256, 8, 1), (8, 256, 256, 8, 1), (8, 128, 64, 32, 1), (8, 256, 128, 16, 1),
     (4, 64, 64, 32, 1), (4, 128, 128, 16, 1), (4, 256, 256, 8, 1), (4, 128, 256, 8, 1),
+    (8, 32, 32, 32, 1), (8, 128, 256, 16, 2), (4, 32, 32, 32, 1), (4, 32, 64, 64, 2), (4, 64, 128, 32, 2),
 ]
 flush = torch.empty(256 << 20, device=DEV)
 for (n, ci, co, d, s) in shapes:

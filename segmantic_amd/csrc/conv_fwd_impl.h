@@ -81,6 +81,10 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
   // fits in <= 64 VGPRs it is fetched BEFORE the halo staging so its latency hides under the
   // staging loads; otherwise the next k-step's fragments are prefetched one step ahead.
   constexpr bool PRE = G::NSTEP * NT <= 16;
+  // otherwise a queue of WD k-steps of fragments runs ahead of the MFMAs: between two uses of a
+  // layer its weights leave the L2s (GBs of activations stream through), so every fetch pays the
+  // HBM latency and a one-step-ahead prefetch serialises NSTEP of them (27 x ~1.5 us measured)
+  constexpr int WD = NT <= 2 ? (G::NSTEP < 4 ? G::NSTEP : 4) : 2;
   // Multi-chunk layers (Cin > CK): the halo tile of chunk c+1 is fetched into registers before
   // the MFMA phase of chunk c (register-staged pipeline) when the register budget allows.
   constexpr int NCH = G::HD * G::HH * G::HW * G::CPR;
@@ -111,12 +115,19 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
     const char* wb = (const char*)p.wfrag +
                      (((int64_t)c * G::NSTEP) * p.ntiles_total + nt0) * 1024 + lane * 16;
     frag_t wall[PRE ? G::NSTEP : 1][NT];
+    frag_t wq[PRE ? 1 : WD][NT];
     if constexpr (PRE) {
 #pragma unroll
       for (int s = 0; s < G::NSTEP; ++s)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           wall[s][j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
+    } else {   // first WD k-steps: in flight under the halo commit and the barrier
+#pragma unroll
+      for (int s = 0; s < WD; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          wq[s][j] = *reinterpret_cast<const frag_t*>(wb + ((int64_t)s * p.ntiles_total + j) * 1024);
     }
     // ---- halo tile of chunk c -> LDS
     if constexpr (PF) {
@@ -131,12 +142,6 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
     __syncthreads();
     if constexpr (PF) {
       if (c + 1 < p.nchunks) fetch(c + 1);
-    }
-    frag_t wnext[NT];
-    if constexpr (!PRE) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        wnext[j] = *reinterpret_cast<const frag_t*>(wb + (int64_t)j * 1024);
     }
 #pragma unroll
     for (int s = 0; s < G::NSTEP; ++s) {
@@ -160,12 +165,12 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
         for (int j = 0; j < NT; ++j) wf[j] = wall[s][j];
       } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = wnext[j];
-        if (s + 1 < G::NSTEP) {
+        for (int j = 0; j < NT; ++j) wf[j] = wq[s % WD][j];
+        if (s + WD < G::NSTEP) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            wnext[j] = *reinterpret_cast<const frag_t*>(
-                wb + ((int64_t)(s + 1) * p.ntiles_total + j) * 1024);
+            wq[s % WD][j] = *reinterpret_cast<const frag_t*>(
+                wb + ((int64_t)(s + WD) * p.ntiles_total + j) * 1024);
         }
       }
 #pragma unroll

@@ -244,23 +244,30 @@ static inline int conv_ks_rows(const segmi_act* out) {
 // stride 2 does not gain (86 -> 97 us) and stays on conv_fwd_impl.h.
 static inline bool conv_ks_ok(int dtype, int cin, int ksize, int stride) {
   static const bool off = getenv("SEGMI_CONV_KS") && atoi(getenv("SEGMI_CONV_KS")) == 0;
-  if (off || ksize != 3 || stride != 1) return false;
+  static const bool s2 = getenv("SEGMI_CONV_KS_S2") && atoi(getenv("SEGMI_CONV_KS_S2")) == 1;
+  static const bool one = !(getenv("SEGMI_CONV_KS_1CH") && atoi(getenv("SEGMI_CONV_KS_1CH")) == 0);
+  if (off || ksize != 3 || (stride != 1 && !s2)) return false;
   const int ck = pick_ck(dtype, cin);
   const int spt = ck / (dtype == SEGMI_F32 ? 4 : 8);
-  return spt == 4 && cin / ck >= 2;
+  return spt == 4 && cin / ck >= (one ? 1 : 2);
 }
 
-template <typename T, int CK>
-static int launch_conv_ks_t(const ConvParams& p, hipStream_t st) {
+template <typename T, int CK, int S>
+static int launch_conv_ks_s(const ConvParams& p, hipStream_t st) {
   const segmi_act o{nullptr, p.N, p.Do, p.Ho, p.Wo, p.Cout, p.Cout};
   const int nt = p.Cout / 16;
   // two output tiles per workgroup (input fragment reuse) unless that leaves < 512 workgroups
   const bool two = nt % 2 == 0 && (int64_t)conv_ks_rows(&o) * (nt / 2) >= 512;
   const bool wide = p.Wo > 8;
-  if (two) return wide ? launch_conv_ks_cfg<T, CK, 3, 1, 2, 2, 4, 16>(p, st)
-                       : launch_conv_ks_cfg<T, CK, 3, 1, 2, 4, 4, 8>(p, st);
-  return wide ? launch_conv_ks_cfg<T, CK, 3, 1, 1, 2, 4, 16>(p, st)
-              : launch_conv_ks_cfg<T, CK, 3, 1, 1, 4, 4, 8>(p, st);
+  if (two) return wide ? launch_conv_ks_cfg<T, CK, 3, S, 2, 2, 4, 16>(p, st)
+                       : launch_conv_ks_cfg<T, CK, 3, S, 2, 4, 4, 8>(p, st);
+  return wide ? launch_conv_ks_cfg<T, CK, 3, S, 1, 2, 4, 16>(p, st)
+              : launch_conv_ks_cfg<T, CK, 3, S, 1, 4, 4, 8>(p, st);
+}
+template <typename T, int CK>
+static int launch_conv_ks_t(const ConvParams& p, int stride, hipStream_t st) {
+  if (stride == 2) return launch_conv_ks_s<T, CK, 2>(p, st);
+  return launch_conv_ks_s<T, CK, 1>(p, st);
 }
 
 }  // namespace segmi

@@ -7,7 +7,7 @@ namespace segmi {
 int conv_mfma_bf16(const ConvParams& p, int ksize, int stride, hipStream_t st) {
   if (conv_ring_zsplit(SEGMI_BF16, p.Cin, ksize, stride, p.N, p.Do, p.Ho, p.Wo) > 0)
     return launch_conv_ring_t<bf16_t>(p, st);
-  if (conv_ks_ok(SEGMI_BF16, p.Cin, ksize, stride)) return launch_conv_ks_t<bf16_t, 32>(p, st);
+  if (conv_ks_ok(SEGMI_BF16, p.Cin, ksize, stride)) return launch_conv_ks_t<bf16_t, 32>(p, stride, st);
   return launch_conv_mfma_t<bf16_t>(p, ksize, stride, st);
 }
 int convt_mfma_bf16(const ConvTParams& p, hipStream_t st) {
