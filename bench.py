@@ -219,10 +219,11 @@ def main():
                 ach = flops / (avg * 1e-3) / 1e12
                 peak = MFMA_PEAK_BF16_TFLOPS if args.precision == "bf16" else MFMA_PEAK_F32_TFLOPS
                 es = 2 if args.precision == "bf16" else 4
-                # Algorithmic bytes per voxel of this launch: 16 channels in + 16 residual + 16 out
-                # (DESIGN.md section 4).  Intensity 864*16/(48*es) = 144 FLOP/B (bf16) is below
-                # the chip ridge (~310 FLOP/B): HBM is the roof that bounds this kernel.
-                abytes = kern_units * 16 * es * 3
+                # Algorithmic bytes per voxel of this launch: 16 channels in + 16 out (DESIGN.md
+                # section 4; the identity residual IS the input tensor and is taken from the LDS
+                # ring, so it is not a second stream).  Intensity 864*16/(32*es) = 216 FLOP/B
+                # (bf16) is below the chip ridge (~310 FLOP/B): HBM is the roof of this kernel.
+                abytes = kern_units * 16 * es * 2
                 gbps = abytes / (avg * 1e-3) / 1e9
                 traffic = None
                 tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -232,7 +233,7 @@ def main():
                     # rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)
                     traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
                 out["roofline"] = {
-                    "kernel": "conv_ring_mfma_kernel (full-resolution 16->16 k3 conv + residual epilogue)",
+                    "kernel": "conv_ring_mfma_kernel (full-resolution 16->16 k3 conv, identity residual from LDS)",
                     "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
                     "frac": gbps / 8000.0, "traffic": traffic,
                     "avg_launch_ms": avg, "launches": len(ms),
