@@ -110,6 +110,15 @@ template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
   return v;
 }
 
+// "Use" a value without emitting an instruction: the compiler must complete the load that
+// produced it HERE.  hipcc's waitcnt insertion cannot prove that a load issued before a loop (bias,
+// PReLU slope, prefetched residual rows) has landed when its first use sits in a conditionally
+// executed block, and then puts s_waitcnt vmcnt(0) in front of EVERY such block -- on gfx9 that
+// also waits for the previous block's global store, serialising an epilogue's stores on the
+// full memory round trip.  Touching the value once, unconditionally, removes all those waits.
+template <typename V> __device__ __forceinline__ void touch_v(V& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void touch_s(float& v) { asm volatile("" : "+s"(v)); }
+
 // sum over the 16 lanes that share (lane>>4): result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
   v += __shfl_xor(v, 1);
