@@ -160,6 +160,28 @@ __global__ __launch_bounds__(256) void conv_fwd_ks_kernel(ConvParams p) {
   }
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.res;
+  f32x4 resv[2][NT];
+  if (resp) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int idx = (wave * 2 + ii) * 16 + r;
+      const int oz = oz0 + idx / (TW * TH), oy = oy0 + (idx / TW) % TH, ox = ox0 + idx % TW;
+      const bool valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
+      const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        resv[ii][j] = valid ? load4<T>(resp + vox * p.ldr + (nt0 + j) * 16 + 4 * g)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) touch_v(resv[ii][j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) touch_v(bias4[j]);
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) touch_v(stg[k]);
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii) {
     const int idx = (wave * 2 + ii) * 16 + r;
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_fwd_ks_kernel(ConvParams p) {
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
         }
         const int co = (nt0 + j) * 16 + 4 * g;
-        if (resp) v += load4<T>(resp + vox * p.ldr + co);
+        if (resp) v += resv[ii][j];
         store4<T>(outp + vox * p.ldo + co, v);
       }
     }

@@ -142,13 +142,47 @@ __device__ __forceinline__ void convt_wave_store(const f32x4 (&acc)[3][4][NT],
     const int idx = vt * 16 + r;
     lvox[vt] = (2 * (idx / (TW * TH)) * p.Ho + 2 * ((idx / TW) % TH)) * p.Wo + 2 * (idx % TW);
   }
+  // residual rows first, all at once (a load -> add -> store chain per tile would serialise the
+  // stores on s_waitcnt vmcnt(0); see touch_v in common.h)
+  f32x4 resv[3][4][NT];
+  if (resp) {
+#pragma unroll
+    for (int ci = 0; ci < kCtNCls[W]; ++ci) {
+      const int cls = kCtCls[W][ci];
+      const int rw = cls & 1, rh = (cls >> 1) & 1, rd = (cls >> 2) & 1;
+      const int cls_vox = (rd * p.Ho + rh) * p.Wo + rw;
+      const T* rb = resp + (tile_vox + cls_vox) * p.ldr + nt0 * 16 + 4 * g;
+#pragma unroll
+      for (int vt = 0; vt < 4; ++vt) {
+        bool valid = true;
+        if constexpr (!FAST) {
+          const int idx = vt * 16 + r;
+          const int oz = 2 * (iz0 + idx / (TW * TH)) + rd;
+          const int oy = 2 * (iy0 + (idx / TW) % TH) + rh;
+          const int ox = 2 * (ix0 + idx % TW) + rw;
+          valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          resv[ci][vt][j] = valid ? load4<T>(rb + (int64_t)lvox[vt] * p.ldr + j * 16)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < kCtNCls[W]; ++ci)
+#pragma unroll
+      for (int vt = 0; vt < 4; ++vt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) touch_v(resv[ci][vt][j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) touch_v(bias4[j]);
 #pragma unroll
   for (int ci = 0; ci < kCtNCls[W]; ++ci) {
     const int cls = kCtCls[W][ci];
     const int rw = cls & 1, rh = (cls >> 1) & 1, rd = (cls >> 2) & 1;
     const int cls_vox = (rd * p.Ho + rh) * p.Wo + rw;
     T* ob = outp + (tile_vox + cls_vox) * p.ldo + nt0 * 16 + 4 * g;
-    const T* rb = resp ? resp + (tile_vox + cls_vox) * p.ldr + nt0 * 16 + 4 * g : nullptr;
 #pragma unroll
     for (int vt = 0; vt < 4; ++vt) {
       bool valid = true;
@@ -171,7 +205,7 @@ __device__ __forceinline__ void convt_wave_store(const f32x4 (&acc)[3][4][NT],
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
           }
-          if (rb) v += load4<T>(rb + (int64_t)lvox[vt] * p.ldr + j * 16);
+          if (resp) v += resv[ci][vt][j];
           store4<T>(ob + (int64_t)lvox[vt] * p.ldo + j * 16, v);
         }
       }
