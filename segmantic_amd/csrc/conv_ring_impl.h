@@ -363,33 +363,38 @@ __global__ __launch_bounds__(256, 2) void conv_ring2_kernel(ConvParams p) {
   }
   const int wrow = wave * 2 * G::HW * G::ROWB;   // the wave's first y-row
 
-  // ---- staging descriptors / prologue: identical to conv_ring_mfma_kernel
+  // ---- staging descriptors.  Index arithmetic is the bottleneck of this kernel family (the first
+  // version spent 83 quarter-rate integer multiplies per wave and step on 64-bit voxel addresses --
+  // more issue cycles than its 112 MFMAs), so everything per-lane is computed ONCE as a 32-bit
+  // offset inside a plane and every per-step quantity is a wave-uniform plane pointer (SALU):
+  // loads and stores use the "SGPR base + VGPR offset" form with no VALU address math at all.
+  constexpr int NLP = (G::PLANE_CHUNKS + 255) / 256;   // 16-byte chunks per thread per plane
   const char* inb = (const char*)p.in;
   const int64_t plane_stride = (int64_t)p.Hi * p.Wi * p.ldi * (int64_t)sizeof(T);
-  const int64_t img_base = (int64_t)n * p.Di * plane_stride;
-  int s_goff[G::NLD], s_loff[G::NLD], s_pl[G::NLD];
+  const char* img = inb + (int64_t)n * p.Di * plane_stride;
+  int g_off[NLP], l_off[NLP];
 #pragma unroll
-  for (int k = 0; k < G::NLD; ++k) {
-    const int i = tid + 256 * k;
-    const int pl = i / G::PLANE_CHUNKS, rem = i % G::PLANE_CHUNKS;
-    const int row = rem / G::CPR, ch = rem % G::CPR;
+  for (int q = 0; q < NLP; ++q) {
+    const int i = tid + 256 * q;
+    const int row = i / G::CPR, ch = i % G::CPR;
     const int hy = row / G::HW, hx = row % G::HW;
     const int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
-    const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-    s_pl[k] = pl < G::TD ? pl : G::TD;
-    s_loff[k] = row * G::ROWB + ch * 16;
-    s_goff[k] = ok ? (int)((((int64_t)y * p.Wi + x) * p.ldi) * (int64_t)sizeof(T)) + ch * 16 : -1;
+    const bool ok = i < G::PLANE_CHUNKS && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    l_off[q] = i < G::PLANE_CHUNKS ? row * G::ROWB + ch * 16 : -1;
+    g_off[q] = ok ? (y * p.Wi + x) * p.ldi * (int)sizeof(T) + ch * 16 : -1;
   }
-  for (int i = tid; i < 6 * G::PLANE_CHUNKS; i += 256) {
-    const int pl = i / G::PLANE_CHUNKS, rem = i % G::PLANE_CHUNKS;
-    const int row = rem / G::CPR, ch = rem % G::CPR;
-    const int hy = row / G::HW, hx = row % G::HW;
-    const int z = z0 + pl - 1, y = oy0 - 1 + hy, x = ox0 - 1 + hx;
-    frag_t val = frag_t{0u, 0u, 0u, 0u};
-    if ((unsigned)z < (unsigned)p.Di && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi)
-      val = *reinterpret_cast<const frag_t*>(inb + img_base + z * plane_stride +
-                                             (((int64_t)y * p.Wi + x) * p.ldi) * (int64_t)sizeof(T) + ch * 16);
-    *reinterpret_cast<frag_t*>(smem + pl * G::PLANE_B + row * G::ROWB + ch * 16) = val;
+  // prologue: planes z0-1 .. z0+4 -> ring slots 0 .. 5
+#pragma unroll
+  for (int pl = 0; pl < 6; ++pl) {
+    const int z = z0 + pl - 1;
+    const char* pp = img + (int64_t)z * plane_stride;
+#pragma unroll
+    for (int q = 0; q < NLP; ++q) {
+      frag_t val = frag_t{0u, 0u, 0u, 0u};
+      if ((unsigned)z < (unsigned)p.Di && g_off[q] >= 0)
+        val = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+      if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + pl * G::PLANE_B + l_off[q]) = val;
+    }
   }
   __syncthreads();
 
@@ -404,30 +409,46 @@ __global__ __launch_bounds__(256, 2) void conv_ring2_kernel(ConvParams p) {
   const T* resp = (const T*)p.res;
   const bool res_in = resp && p.res == p.in && p.ldr == p.ldi && p.Cin == p.Cout;
   const int co = blockIdx.y * 16 + 4 * g;
+  // per-lane element offsets of the wave's two output rows inside an output plane
+  unsigned o_off[2], r_off[2];
+  bool row_ok[2];
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro) {
+    const int oy = oy0 + 2 * wave + ro, ox = ox0 + r;
+    row_ok[ro] = oy < p.Ho && ox < p.Wo;
+    o_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldo + co);
+    r_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldr + co);
+  }
+  const int64_t oplane = (int64_t)p.Ho * p.Wo * p.ldo, rplane = (int64_t)p.Ho * p.Wo * p.ldr;
 
   for (int step = 0; step < nsteps_z; ++step) {
     const int zb = step * G::TD;
-    frag_t stg[G::NLD];
     const bool more = step + 1 < nsteps_z;
+    // ---- issue the global loads of the NEXT step's 4 new planes (z = z0 + zb + 5 .. + 8)
+    frag_t stg[G::TD][NLP];
 #pragma unroll
-    for (int k = 0; k < G::NLD; ++k) {
-      stg[k] = frag_t{0u, 0u, 0u, 0u};
-      const int z = z0 + zb + 5 + s_pl[k];
-      if (more && s_pl[k] < G::TD && s_goff[k] >= 0 && z < p.Di)
-        stg[k] = *reinterpret_cast<const frag_t*>(inb + img_base + z * plane_stride + s_goff[k]);
+    for (int pl = 0; pl < G::TD; ++pl) {
+      const int z = z0 + zb + 5 + pl;
+      const char* pp = img + (int64_t)z * plane_stride;
+      const bool zok = more && z < p.Di;
+#pragma unroll
+      for (int q = 0; q < NLP; ++q) {
+        stg[pl][q] = frag_t{0u, 0u, 0u, 0u};
+        if (zok && g_off[q] >= 0) stg[pl][q] = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+      }
     }
     // residual rows of this step's outputs (4 planes x 2 rows), unless they are the input itself
     typename Raw4<T>::type resv[4][2];
     if (resp && !res_in) {
 #pragma unroll
-      for (int zi = 0; zi < 4; ++zi)
+      for (int zi = 0; zi < 4; ++zi) {
+        const int oz = z0 + zb + zi;
+        const T* rp = resp + ((int64_t)n * p.Do + oz) * rplane;
 #pragma unroll
-        for (int ro = 0; ro < 2; ++ro) {
-          const int oz = z0 + zb + zi, oy = oy0 + 2 * wave + ro, ox = ox0 + r;
-          const bool valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
-          const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
-          resv[zi][ro] = valid ? Raw4<T>::ld(resp + vox * p.ldr + co) : typename Raw4<T>::type{};
-        }
+        for (int ro = 0; ro < 2; ++ro)
+          resv[zi][ro] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(rp + r_off[ro])
+                                                   : typename Raw4<T>::type{};
+      }
     }
     // ---- compute: input plane c (z = zb - 1 + c) lives in ring slot (zb + c) % R
     f32x4 acc[4][2];
@@ -463,17 +484,21 @@ __global__ __launch_bounds__(256, 2) void conv_ring2_kernel(ConvParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- write the prefetched planes into the free ring slots (zb+6 .. zb+9 mod R)
+    if (more) {
 #pragma unroll
-    for (int k = 0; k < G::NLD; ++k) {
-      if (more && s_pl[k] < G::TD) {
-        const int slot = (zb + 6 + s_pl[k]) % G::R;
-        *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + s_loff[k]) = stg[k];
+      for (int pl = 0; pl < G::TD; ++pl) {
+        const int slot = (zb + 6 + pl) % G::R;
+#pragma unroll
+        for (int q = 0; q < NLP; ++q)
+          if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = stg[pl][q];
       }
     }
     // every staging register is dead from here on; say so on ALL control-flow paths, otherwise
     // each conditionally executed epilogue block below re-waits (vmcnt(0)) before reusing them
 #pragma unroll
-    for (int k = 0; k < G::NLD; ++k) touch_v(stg[k]);
+    for (int pl = 0; pl < G::TD; ++pl)
+#pragma unroll
+      for (int q = 0; q < NLP; ++q) touch_v(stg[pl][q]);
     if (res_in) {   // centre plane of output plane zi is input plane c = zi + 1
 #pragma unroll
       for (int zi = 0; zi < 4; ++zi)
@@ -490,23 +515,23 @@ __global__ __launch_bounds__(256, 2) void conv_ring2_kernel(ConvParams p) {
     }
     // ---- epilogue of this step
 #pragma unroll
-    for (int zi = 0; zi < 4; ++zi)
+    for (int zi = 0; zi < 4; ++zi) {
+      const int oz = z0 + zb + zi;
+      T* op = outp + ((int64_t)n * p.Do + oz) * oplane;   // wave-uniform plane pointer
 #pragma unroll
       for (int ro = 0; ro < 2; ++ro) {
-        const int oz = z0 + zb + zi, oy = oy0 + 2 * wave + ro, ox = ox0 + r;
-        const bool valid = oz < p.Do && oy < p.Ho && ox < p.Wo;
-        const int64_t vox = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
         f32x4 v = acc[zi][ro] + bias4;
-        if (valid) {
+        if (oz < p.Do && row_ok[ro]) {
           if (p.stats) { ssum += v; ssq += v * v; }
           if (has_alpha) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
           }
           if (resp) v += Raw4<T>::cvt(resv[zi][ro]);
-          store4<T>(outp + vox * p.ldo + co, v);
+          store4<T>(op + o_off[ro], v);
         }
       }
+    }
     __syncthreads();
   }
 
