@@ -234,6 +234,27 @@ int segmi_normalize_intensity(float* x, int c, int64_t nvox, void* workspace, vo
 int segmi_crop_patches(const segmi_act* image, const float* label, const int32_t* starts_host,
                        const uint8_t* flips_host, int count, int dst_dtype,
                        const segmi_act* out_image, float* out_label, void* stream);
+/* The same sampler with the spatial augmentation of monai_unet.py:181-191 (RandRotated about the
+ * three axes, RandZoomd keep_size) composed into the gather: a patch voxel goes (flip, crop origin)
+ * -> index in the augmented volume -> index_map_host (12 doubles, row-major 3x4, (x,y,z,1) ->
+ * continuous source index) -> image trilinear with border clamping, label nearest; positions
+ * outside the augmented volume's extent (the SpatialPadd region) are 0. */
+int segmi_warp_crop_patches(const segmi_act* image, const float* label, const int32_t* starts_host,
+                            const uint8_t* flips_host, int count, const double* index_map_host,
+                            int dst_dtype, const segmi_act* out_image, float* out_label,
+                            void* stream);
+/* Intensity augmentation of monai_unet.py:205-208 on `count` dense f32 NDHWC patches
+ * [count][rd][rh][rw][c], in place, in the reference's order: RandAdjustContrastd (gamma),
+ * RandHistogramShiftd (nctrl floating control points in [0,1] per patch, ascending),
+ * RandBiasFieldd (20 degree-3 Legendre coefficients per patch).  Each *_on_host (uint8[count],
+ * nullable = skip the transform) selects the patches a transform applies to; the random draws
+ * are the caller's.  workspace >= segmi_intensity_workspace(count) bytes. */
+int64_t segmi_intensity_workspace(int count);
+int segmi_intensity_augment(float* patches, int count, int rd, int rh, int rw, int c,
+                            const uint8_t* contrast_on_host, const float* gamma_host,
+                            const uint8_t* hist_on_host, const float* ctrl_host, int nctrl,
+                            const uint8_t* bias_on_host, const float* coef_host, void* workspace,
+                            void* stream);
 
 #ifdef __cplusplus
 }

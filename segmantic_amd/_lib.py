@@ -82,6 +82,9 @@ SIGNATURES = {
     "segmi_normalize_workspace": (_i64, [_i, _i64]),
     "segmi_normalize_intensity": (_i, [_P, _i, _i64, _P, _P]),
     "segmi_crop_patches": (_i, [_AP, _P, _P, _P, _i, _i, _AP, _P, _P]),
+    "segmi_warp_crop_patches": (_i, [_AP, _P, _P, _P, _i, _P, _i, _AP, _P, _P]),
+    "segmi_intensity_workspace": (_i64, [_i]),
+    "segmi_intensity_augment": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _i, _P, _P, _P, _P]),
 }
 
 

@@ -109,6 +109,27 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   // phase of tile t and land in LDS after it (global latency hides under compute).
   constexpr int NLY = (G::NV * G::YCPR + 255) / 256, NLX = (G::XROWS * G::XCPR + 255) / 256;
   frag_t ry[NLY], rx[NLX];
+  // Step-invariant per-lane descriptors: 32-bit byte offset inside a tile and packed tile-local
+  // coordinates.  Per tile only a wave-uniform base pointer and uniform limits change, so a load
+  // costs ~6 VALU ops of bounds checking instead of a 64-bit voxel-address multiply chain.
+  int y_goff[NLY], x_goff[NLX];
+  unsigned y_pk[NLY], x_pk[NLX];
+#pragma unroll
+  for (int k = 0; k < NLY; ++k) {
+    const int i = tid + 256 * k;
+    const int v = i / G::YCPR, ch = i % G::YCPR;
+    const int vz = v / (TW * TH), vy = (v / TW) % TH, vx = v % TW;
+    y_goff[k] = ((vz * p.Hy + vy) * p.Wy + vx) * p.ldy * (int)sizeof(T) + ch * 16;
+    y_pk[k] = i < G::NV * G::YCPR ? (unsigned)(vz | (vy << 8) | (vx << 16)) : 0xffffffffu;
+  }
+#pragma unroll
+  for (int k = 0; k < NLX; ++k) {
+    const int i = tid + 256 * k;
+    const int v = i / G::XCPR, ch = i % G::XCPR;
+    const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
+    x_goff[k] = ((hz * p.Hx + hy) * p.Wx + hx) * p.ldx * (int)sizeof(T) + ch * 16;
+    x_pk[k] = i < G::XROWS * G::XCPR ? (unsigned)(hz | (hy << 8) | (hx << 16)) : 0xffffffffu;
+  }
   auto fetch = [&](int tile) {
     int t = tile;
     const int txi = t % p.tx; t /= p.tx;
@@ -117,29 +138,26 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     const int n = t / p.tz;
     const int oz0 = tzi * TD, oy0 = tyi * TH, ox0 = txi * TW;
     const int iz0 = oz0 * S - G::PAD, iy0 = oy0 * S - G::PAD, ix0 = ox0 * S - G::PAD;
+    const char* ybase = yb + (((((int64_t)n * p.Dy + oz0) * p.Hy + oy0) * p.Wy + ox0) * p.ldy + co0) *
+                                 (int64_t)sizeof(T);
+    const char* xbase = xb + (((((int64_t)n * p.Dx + iz0) * p.Hx + iy0) * p.Wx + ix0) * p.ldx + ci0) *
+                                 (int64_t)sizeof(T);
+    const unsigned lz = p.Dy - oz0, ly = p.Hy - oy0, lx = p.Wy - ox0;
 #pragma unroll
-    for (int k = 0; k < NLY; ++k) {        // dY tile [NV][16*CT]
-      const int i = tid + 256 * k;
-      const int v = i / G::YCPR, ch = i % G::YCPR;
-      const int z = oz0 + v / (TW * TH), y = oy0 + (v / TW) % TH, x = ox0 + v % TW;
+    for (int k = 0; k < NLY; ++k) {        // dY tile [NV][16*CTO]
+      const unsigned pk = y_pk[k];
       ry[k] = frag_t{0u, 0u, 0u, 0u};
-      if (i < G::NV * G::YCPR && z < p.Dy && y < p.Hy && x < p.Wy) {
-        const int64_t e = ((((int64_t)n * p.Dy + z) * p.Hy + y) * p.Wy + x) * p.ldy + co0;
-        ry[k] = *reinterpret_cast<const frag_t*>(yb + e * (int64_t)sizeof(T) + ch * 16);
-      }
+      if ((pk & 255u) < lz && ((pk >> 8) & 255u) < ly && (pk >> 16) < lx)
+        ry[k] = *reinterpret_cast<const frag_t*>(ybase + (unsigned)y_goff[k]);
     }
 #pragma unroll
-    for (int k = 0; k < NLX; ++k) {        // X halo tile [HD*HH*HW][16*CT]
-      const int i = tid + 256 * k;
-      const int v = i / G::XCPR, ch = i % G::XCPR;
-      const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
-      const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
+    for (int k = 0; k < NLX; ++k) {        // X halo tile [HD*HH*HW][16*CTI]
+      const unsigned pk = x_pk[k];
       rx[k] = frag_t{0u, 0u, 0u, 0u};
-      if (i < G::XROWS * G::XCPR && (unsigned)z < (unsigned)p.Dx && (unsigned)y < (unsigned)p.Hx &&
-          (unsigned)x < (unsigned)p.Wx) {
-        const int64_t e = ((((int64_t)n * p.Dx + z) * p.Hx + y) * p.Wx + x) * p.ldx + ci0;
-        rx[k] = *reinterpret_cast<const frag_t*>(xb + e * (int64_t)sizeof(T) + ch * 16);
-      }
+      if (pk != 0xffffffffu && (unsigned)((int)(pk & 255u) + iz0) < (unsigned)p.Dx &&
+          (unsigned)((int)((pk >> 8) & 255u) + iy0) < (unsigned)p.Hx &&
+          (unsigned)((int)(pk >> 16) + ix0) < (unsigned)p.Wx)
+        rx[k] = *reinterpret_cast<const frag_t*>(xbase + (unsigned)x_goff[k]);
     }
   };
   auto commit = [&]() {
@@ -247,6 +265,10 @@ static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
   p.ty = cdiv(p.Hy, TH);
   p.tx = cdiv(p.Wy, TW);
   p.ntiles = p.N * p.tz * p.ty * p.tx;
+  // 32-bit byte offsets inside one staged tile
+  SEGMI_CHECK_ARG((int64_t)G::HD * p.Hx * p.Wx * p.ldx * (int64_t)sizeof(T) < (1ll << 31) &&
+                      (int64_t)TD * p.Hy * p.Wy * p.ldy * (int64_t)sizeof(T) < (1ll << 31),
+                  "conv3d_wgrad: plane too large for the MFMA kernel's 32-bit tile offsets");
   p.ci_chunks = p.Cin / (16 * CTI);
   const int co_chunks = p.Cout / (16 * CTO);
   dim3 grid((unsigned)gx_hint, (unsigned)(co_chunks * p.ci_chunks));

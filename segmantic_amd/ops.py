@@ -404,3 +404,45 @@ def crop_patches(image, label, starts, flips, out_image, out_label) -> None:
     check(lib.segmi_crop_patches(C.byref(a), _ptr(label), p, flp, arr.shape[0],
                                  dtype_code(out_image), C.byref(b), _ptr(out_label),
                                  _stream()), "crop_patches")
+
+
+def warp_crop_patches(image, label, starts, flips, index_map, out_image, out_label) -> None:
+    """crop_patches with a 3x4 affine (augmented index (x,y,z,1) -> source index) composed in."""
+    a, b = act(image), act(out_image)
+    arr, p = _starts(starts, 4)
+    flp = None
+    if flips is not None:
+        fl = np.ascontiguousarray(np.asarray(flips, dtype=np.uint8))
+        flp = fl.ctypes.data_as(C.c_void_p)
+    m = np.ascontiguousarray(np.asarray(index_map, dtype=np.float64).reshape(12))
+    check(lib.segmi_warp_crop_patches(C.byref(a), _ptr(label), p, flp, arr.shape[0],
+                                      m.ctypes.data_as(C.c_void_p), dtype_code(out_image),
+                                      C.byref(b), _ptr(out_label), _stream()), "warp_crop_patches")
+
+
+def intensity_augment(patches, contrast=None, hist=None, bias=None) -> None:
+    """In-place RandAdjustContrast / RandHistogramShift / RandBiasField on f32 NDHWC patches.
+
+    contrast = (on uint8[n], gamma f32[n]); hist = (on, ctrl f32[n][k]); bias = (on, coef f32[n][20])."""
+    _require_device(patches)
+    if patches.dtype != torch.float32 or patches.dim() != 5 or not patches.is_contiguous():
+        raise ValueError("intensity_augment: dense float32 [n, d, h, w, c] patches expected")
+    n, rd, rh, rw, c = patches.shape
+    ws = torch.empty(int(lib.segmi_intensity_workspace(n)), dtype=torch.uint8, device=patches.device)
+    keep = []
+
+    def arr(x, dt):
+        if x is None:
+            return None
+        a = np.ascontiguousarray(np.asarray(x, dtype=dt))
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    con, gam = (contrast if contrast is not None else (None, None))
+    hon, ctl = (hist if hist is not None else (None, None))
+    bon, cof = (bias if bias is not None else (None, None))
+    nctrl = int(np.asarray(ctl).shape[1]) if ctl is not None else 0
+    check(lib.segmi_intensity_augment(_ptr(patches), n, rd, rh, rw, c, arr(con, np.uint8),
+                                      arr(gam, np.float32), arr(hon, np.uint8), arr(ctl, np.float32),
+                                      nctrl, arr(bon, np.uint8), arr(cof, np.float32), _ptr(ws),
+                                      _stream()), "intensity_augment")

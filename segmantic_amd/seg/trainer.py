@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .augment import draw_intensity, draw_spatial, forward_point, to_index_map_xyz
 from .distributed import broadcast_buffers, env_world, init_distributed
 from .pipeline import PredictPipeline
 
@@ -43,9 +44,14 @@ class CachedVolumes:
         return len(self.items)
 
 
-def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, num_classes: int):
+def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, num_classes: int,
+                 spatial: Optional[np.ndarray] = None):
     """MONAI ``generate_label_classes_crop_centers`` + ``correct_crop_centers`` with
-    ratios = [0, 1, 1, ...] (background never chosen as a centre, monai_unet.py:201)."""
+    ratios = [0, 1, 1, ...] (background never chosen as a centre, monai_unet.py:201).
+
+    ``spatial`` (the pull-back map of ``augment.draw_spatial``): the centre voxel is drawn from the
+    stored label's class lists and carried into the augmented volume, where the reference would
+    have drawn it from the resampled label."""
     shape = list(item["label"].shape[1:])
     ratios = np.array([0.0 if c == 0 else 1.0 for c in range(num_classes)])
     counts = np.array([int(t.numel()) for t in item["class_idx"]])
@@ -60,6 +66,8 @@ def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, 
         pos.append(int(rng.randint(counts[c])))
     flat = torch.stack([item["class_idx"][c][p] for c, p in zip(picks, pos)]).cpu().numpy()
     centers = np.stack(np.unravel_index(flat, shape), 1)
+    if spatial is not None:
+        centers = np.stack([np.rint(forward_point(spatial, c)).astype(np.int64) for c in centers])
     starts = []
     for ctr in centers:
         st = []
@@ -85,14 +93,22 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
     imgs, labs = [], []
     for vid in vol_ids:
         it = cache.items[vid]
-        starts = crop_centers(rng, it, roi, net.num_samples, net.num_classes)
+        spatial = draw_spatial(rng, it["label"].shape[1:]) if net.augment_spatial else None
+        starts = crop_centers(rng, it, roi, net.num_samples, net.num_classes, spatial)
         C = it["image"].shape[0]
         src = it["image"].permute(1, 2, 3, 0).contiguous()[None]            # NDHWC, n = 1
         out_i = torch.empty((len(starts), roi[0], roi[1], roi[2], C), dtype=torch.float32, device=dev)
         out_l = torch.empty((len(starts), roi[0], roi[1], roi[2]), dtype=torch.float32, device=dev)
         flips = [(int(rng.rand() < 0.2)) | (int(rng.rand() < 0.2) << 1) | (int(rng.rand() < 0.2) << 2)
                  for _ in starts]
-        ops.crop_patches(src, it["label"][0].contiguous(), [[0] + s for s in starts], flips, out_i, out_l)
+        if spatial is None:
+            ops.crop_patches(src, it["label"][0].contiguous(), [[0] + s for s in starts], flips, out_i, out_l)
+        else:
+            ops.warp_crop_patches(src, it["label"][0].contiguous(), [[0] + s for s in starts], flips,
+                                  to_index_map_xyz(spatial), out_i, out_l)
+        if net.augment_intensity:
+            con, hist, bias = draw_intensity(rng, len(starts))
+            ops.intensity_augment(out_i, con, hist, bias)
         imgs.append(out_i.permute(0, 4, 1, 2, 3))
         labs.append(out_l.unsqueeze(1))
     return {"image": torch.cat(imgs).contiguous(), "label": torch.cat(labs).contiguous()}
@@ -100,11 +116,6 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
 
 def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_ids,
         ckpt_name: Callable, batch_volumes: int = 2, seed: int = 0):
-    if net.augment_intensity or net.augment_spatial:
-        raise NotImplementedError(
-            "segmantic_amd: 'augment_intensity' / 'augment_spatial' (MONAI RandRotate/RandZoom/"
-            "intensity transforms, reference monai_unet.py:181-212) are not implemented on the GPU "
-            "sampler yet; the default crop + flip augmentation is")
     if len(list(gpu_ids or [0])) > 1 and env_world()[2] == 1:
         raise RuntimeError(
             "segmantic_amd: several gpu_ids need one process per GPU: launch with "

@@ -273,3 +273,37 @@ def test_nifti_roundtrip_and_orientation(tmp_path):
     j = np.linalg.solve(A2, A @ i)
     assert ras[0][tuple(int(round(x)) for x in j[:3])] == v
     assert torch.equal(from_ras(ras, rec), vol)
+
+
+def test_augmentation_draws_follow_the_reference_distributions():
+    """monai_unet.py:181-212: four spatial transforms at prob 0.2 each, invertible composed map,
+    monotone histogram control points, 20 bias coefficients in [0, 0.1)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "segmi_augment", Path(__file__).resolve().parents[1] / "segmantic_amd" / "seg" / "augment.py")
+    aug = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(aug)
+    rng = np.random.RandomState(0)
+    fired = 0
+    for _ in range(2000):
+        m = aug.draw_spatial(rng, (40, 50, 60))
+        if m is None:
+            continue
+        fired += 1
+        p = aug.forward_point(m, (10, 20, 30))
+        assert np.allclose((m @ np.array([*p, 1.0]))[:3], (10, 20, 30))
+        ctr = np.array([19.5, 24.5, 29.5, 1.0])
+        assert np.allclose(m @ ctr, ctr)                       # rotations and zoom keep the centre
+        s = np.linalg.det(m[:3, :3]) ** (1 / 3)
+        assert 1 / 1.3 - 1e-9 <= s <= 1 / 0.8 + 1e-9            # pull-back scale = 1 / zoom
+    assert abs(fired / 2000 - (1 - 0.8 ** 4)) < 0.04
+    xyz = aug.to_index_map_xyz(np.arange(16, dtype=float).reshape(4, 4))
+    assert xyz.shape == (3, 4) and xyz[0, 0] == 10 and xyz[2, 3] == 3 and xyz[0, 3] == 11
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        con, hist, bias = aug.draw_intensity(rng, 64)
+    assert hist[1].shape == (64, 10) and np.all(np.diff(hist[1], axis=1) >= 0)
+    assert np.all(hist[1][:, 0] == 0) and np.all(hist[1][:, -1] == 1)
+    assert bias[1].shape == (64, 20) and bias[1].min() >= 0 and bias[1].max() < 0.1
+    assert con[1].min() >= 0.5 and con[1].max() <= 4.5
