@@ -255,6 +255,17 @@ int segmi_intensity_augment(float* patches, int count, int rd, int rh, int rw, i
                             const uint8_t* hist_on_host, const float* ctrl_host, int nctrl,
                             const uint8_t* bias_on_host, const float* coef_host, void* workspace,
                             void* stream);
+/* k-space augmentation of monai_unet.py:209-210 on the same patch layout, channel-wise, in place:
+ * RandGibbsNoised (spectrum outside radius (1-alpha)*max(shape)*sqrt(2)/2 of the centred k-space
+ * zeroed) then RandKSpaceSpikeNoised (one bin at spike_loc_host int32[count][3] = (z,y,x) of the
+ * centred k-space set to magnitude exp(2.5 * mean log|K| * (0.95 + 0.15 * spike_u)), phase kept).
+ * 3-D DFT of any extents <= 512 (direct per-axis transform in LDS; only selected patches are
+ * transformed).  workspace >= segmi_kspace_workspace(count, rd, rh, rw) bytes. */
+int64_t segmi_kspace_workspace(int count, int rd, int rh, int rw);
+int segmi_kspace_augment(float* patches, int count, int rd, int rh, int rw, int c,
+                         const uint8_t* gibbs_on_host, const float* gibbs_alpha_host,
+                         const uint8_t* spike_on_host, const int32_t* spike_loc_host,
+                         const float* spike_u_host, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

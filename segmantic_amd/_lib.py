@@ -85,6 +85,8 @@ SIGNATURES = {
     "segmi_warp_crop_patches": (_i, [_AP, _P, _P, _P, _i, _P, _i, _AP, _P, _P]),
     "segmi_intensity_workspace": (_i64, [_i]),
     "segmi_intensity_augment": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _i, _P, _P, _P, _P]),
+    "segmi_kspace_workspace": (_i64, [_i, _i, _i, _i]),
+    "segmi_kspace_augment": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

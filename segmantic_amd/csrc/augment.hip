@@ -285,3 +285,220 @@ int segmi_intensity_augment(float* patches, int count, int rd, int rh, int rw, i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// k-space augmentations (RandGibbsNoised, RandKSpaceSpikeNoised; monai_unet.py:209-210).
+// The patches are small (<= 160^3) and the transforms fire with probability 0.2, so the 3-D DFT
+// is three passes of a direct O(N^2) per-line transform (any N <= 512, no radix restrictions --
+// the reference's default patch is 96^3): 16 lines of one axis staged in LDS per workgroup with
+// the N twiddles, every thread accumulating N/16 outputs.  ~6 GFLOP per 128^3 patch and pass set.
+//
+// The reference applies mask / spike to fftshift(fftn(ifftshift(x))) and undoes the shifts after
+// the inverse transform.  A circular shift is a unit-modulus phase ramp in k-space, which commutes
+// with the pointwise mask and with "replace one bin's magnitude, keep its phase"; so both
+// transforms are evaluated on the plain fftn(x) with the mask / spike index un-shifted:
+// shifted index i  <->  plain index (i - N/2) mod N.
+namespace segmi {
+
+typedef float2 cplx;
+
+__global__ __launch_bounds__(256) void dft_axis_kernel(cplx* __restrict__ buf, int N, int64_t stride,
+                                                       int64_t inner, int64_t nlines, int inverse) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  cplx* tw = reinterpret_cast<cplx*>(dsm);          // [N]
+  cplx* ln = tw + N;                                 // [16][N + 1]
+  const int tid = threadIdx.x;
+  for (int m = tid; m < N; m += 256) {
+    float s, c;
+    sincospif(2.0f * (float)m / (float)N, &s, &c);
+    tw[m] = cplx{c, inverse ? s : -s};
+  }
+  const int64_t l0 = (int64_t)blockIdx.x * 16;
+  const int li = tid % 16, k0 = tid / 16;
+  // line l -> (outer, in) with base offset outer * N * stride + in   (in < inner == stride)
+  for (int e = tid; e < 16 * N; e += 256) {
+    const int l = e % 16, n = e / 16;
+    const int64_t line = l0 + l;
+    cplx v = cplx{0.f, 0.f};
+    if (line < nlines) v = buf[(line / inner) * N * stride + (line % inner) + (int64_t)n * stride];
+    ln[l * (N + 1) + n] = v;
+  }
+  __syncthreads();
+  const int64_t line = l0 + li;
+  const float scale = inverse ? 1.0f / (float)N : 1.0f;
+  for (int k = k0; k < N; k += 16) {
+    float ar = 0.f, ai = 0.f;
+    int idx = 0;
+    for (int n = 0; n < N; ++n) {
+      const cplx x = ln[li * (N + 1) + n], w = tw[idx];
+      ar += x.x * w.x - x.y * w.y;
+      ai += x.x * w.y + x.y * w.x;
+      idx += k;
+      if (idx >= N) idx -= N;
+    }
+    if (line < nlines)
+      buf[(line / inner) * N * stride + (line % inner) + (int64_t)k * stride] = cplx{ar * scale, ai * scale};
+  }
+}
+
+struct KspaceParams {   // indexed by SLOT: only the patches a transform fired for are transformed
+  int n;
+  unsigned char src[kMaxCrops];    // slot -> patch index
+  unsigned char gibbs_on[kMaxCrops], spike_on[kMaxCrops];
+  float gibbs_r[kMaxCrops];        // mask radius (1 - alpha) * max(shape) * sqrt(2) / 2
+  int spike_loc[kMaxCrops][3];     // (z, y, x) in the SHIFTED k-space, as the reference draws it
+  float spike_u[kMaxCrops];        // U(0,1): intensity = mean(log|K|) * 2.5 * (0.95 + 0.15 u)
+};
+
+__global__ void real_to_cplx_kernel(const float* __restrict__ x, cplx* __restrict__ k, int64_t per,
+                                    int C, int ch, KspaceParams p) {
+  const int pidx = blockIdx.y;
+  if (!(p.gibbs_on[pidx] | p.spike_on[pidx])) return;
+  const int64_t src = p.src[pidx];
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256)
+    k[(int64_t)pidx * per + i] = cplx{x[(src * per + i) * C + ch], 0.f};
+}
+__global__ void cplx_to_real_kernel(const cplx* __restrict__ k, float* __restrict__ x, int64_t per,
+                                    int C, int ch, KspaceParams p) {
+  const int pidx = blockIdx.y;
+  if (!(p.gibbs_on[pidx] | p.spike_on[pidx])) return;
+  const int64_t src = p.src[pidx];
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256)
+    x[(src * per + i) * C + ch] = k[(int64_t)pidx * per + i].x;
+}
+// GibbsNoise._apply_mask on the un-shifted spectrum
+__global__ void gibbs_mask_kernel(cplx* __restrict__ k, int rd, int rh, int rw, KspaceParams p) {
+  const int pidx = blockIdx.y;
+  if (!p.gibbs_on[pidx]) return;
+  const int64_t per = (int64_t)rd * rh * rw;
+  const float r = p.gibbs_r[pidx];
+  const float cz = (rd - 1) * 0.5f, cy = (rh - 1) * 0.5f, cx = (rw - 1) * 0.5f;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % rw), y = (int)((i / rw) % rh), z = (int)(i / ((int64_t)rw * rh));
+    const float sz = (float)((z + rd / 2) % rd) - cz, sy = (float)((y + rh / 2) % rh) - cy,
+                sx = (float)((x + rw / 2) % rw) - cx;       // position in the shifted spectrum
+    if (sqrtf(sz * sz + sy * sy + sx * sx) > r) k[(int64_t)pidx * per + i] = cplx{0.f, 0.f};
+  }
+}
+// mean over the spectrum of log(|K| + 1e-10): per-workgroup partials (f32), summed in order
+__global__ __launch_bounds__(256) void logabs_partial_kernel(const cplx* __restrict__ k, int64_t per,
+                                                             int chunks, KspaceParams p,
+                                                             float* __restrict__ part) {
+  __shared__ float sm[256];
+  const int pidx = blockIdx.y, chunk = blockIdx.x;
+  float s = 0.f;
+  if (p.spike_on[pidx]) {
+    const int64_t lo = per * chunk / chunks, hi = per * (chunk + 1) / chunks;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+      const cplx v = k[(int64_t)pidx * per + i];
+      s += logf(sqrtf(v.x * v.x + v.y * v.y) + 1e-10f);
+    }
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(int64_t)pidx * chunks + chunk] = sm[0];
+}
+// KSpaceSpikeNoise._set_spike: |K[loc]| := exp(intensity), phase kept
+__global__ void spike_kernel(cplx* __restrict__ k, int rd, int rh, int rw, int chunks,
+                             const float* __restrict__ part, KspaceParams p) {
+  const int pidx = blockIdx.x;
+  if (!p.spike_on[pidx] || threadIdx.x != 0) return;
+  const int64_t per = (int64_t)rd * rh * rw;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += (double)part[(int64_t)pidx * chunks + c];
+  const float mean = (float)(s / (double)per) * 2.5f;
+  const float inten = mean * (0.95f + 0.15f * p.spike_u[pidx]);
+  const int z = ((p.spike_loc[pidx][0] - rd / 2) % rd + rd) % rd;
+  const int y = ((p.spike_loc[pidx][1] - rh / 2) % rh + rh) % rh;
+  const int x = ((p.spike_loc[pidx][2] - rw / 2) % rw + rw) % rw;
+  cplx* q = k + (int64_t)pidx * per + ((int64_t)z * rh + y) * rw + x;
+  const float mag = sqrtf(q->x * q->x + q->y * q->y);
+  const float a = expf(inten);
+  // angle(0) = 0 in the reference (torch.angle), i.e. a positive real spike
+  *q = mag > 0.f ? cplx{q->x / mag * a, q->y / mag * a} : cplx{a, 0.f};
+}
+
+static int dft3d(cplx* buf, int count, int rd, int rh, int rw, int inverse, hipStream_t st) {
+  const int64_t per = (int64_t)rd * rh * rw;
+  const int dims[3] = {rw, rh, rd};
+  const int64_t strides[3] = {1, rw, (int64_t)rw * rh};
+  for (int a = 0; a < 3; ++a) {
+    const int N = dims[a];
+    const int64_t nlines = per / N * count;
+    // lines of axis a inside the [count * per] buffer: for the contiguous axis a line is
+    // `outer`-indexed (inner = 1); for the others consecutive lines are adjacent in memory
+    const size_t lds = (size_t)(N + 16 * (N + 1)) * sizeof(cplx);
+    hipLaunchKernelGGL(dft_axis_kernel, (unsigned)cdiv64(nlines, 16), 256, lds, st, buf, N,
+                       strides[a], strides[a], nlines, inverse);
+  }
+  SEGMI_LAUNCH_CHECK("kspace_augment(dft)");
+  return SEGMI_OK;
+}
+
+}  // namespace segmi
+
+extern "C" {
+
+int64_t segmi_kspace_workspace(int count, int rd, int rh, int rw) {
+  return (int64_t)count * rd * rh * rw * 8 + (int64_t)count * 256 * 4 + 256;
+}
+
+int segmi_kspace_augment(float* patches, int count, int rd, int rh, int rw, int c,
+                         const uint8_t* gibbs_on_host, const float* gibbs_alpha_host,
+                         const uint8_t* spike_on_host, const int32_t* spike_loc_host,
+                         const float* spike_u_host, void* workspace, void* stream) {
+  SEGMI_CHECK_ARG(patches && workspace && count > 0 && count <= kMaxCrops && rd > 0 && rh > 0 &&
+                      rw > 0 && c > 0, "kspace_augment: bad arguments (1..%d patches)", kMaxCrops);
+  SEGMI_CHECK_ARG((!gibbs_on_host || gibbs_alpha_host) && (!spike_on_host || (spike_loc_host && spike_u_host)),
+                  "kspace_augment: missing parameter array");
+  if (rd > 512 || rh > 512 || rw > 512) SEGMI_UNSUPPORTED("kspace_augment: patch extents up to 512");
+  const int mx = rd > rh ? (rd > rw ? rd : rw) : (rh > rw ? rh : rw);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = (int64_t)rd * rh * rw;
+  cplx* buf = (cplx*)workspace;
+  float* part = (float*)((char*)workspace + (int64_t)count * per * 8);
+  const int chunks = 256;
+  const int gx = grid_1d(per, 1024);
+  // the reference order is Gibbs then spike, each with its own forward / inverse transform and a
+  // real-part projection in between; channel_wise: every channel is transformed on its own
+  for (int pass = 0; pass < 2; ++pass) {
+    KspaceParams q{};
+    int ns = 0;
+    for (int i = 0; i < count; ++i) {
+      if (pass == 0 && gibbs_on_host && gibbs_on_host[i]) {
+        q.src[ns] = (unsigned char)i; q.gibbs_on[ns] = 1;
+        q.gibbs_r[ns] = (1.0f - gibbs_alpha_host[i]) * (float)mx * 1.41421356f / 2.0f;
+        ++ns;
+      } else if (pass == 1 && spike_on_host && spike_on_host[i]) {
+        q.src[ns] = (unsigned char)i; q.spike_on[ns] = 1;
+        for (int d = 0; d < 3; ++d) q.spike_loc[ns][d] = spike_loc_host[3 * i + d];
+        q.spike_u[ns] = spike_u_host[i];
+        ++ns;
+      }
+    }
+    if (ns == 0) continue;
+    q.n = ns;
+    for (int ch = 0; ch < c; ++ch) {
+      hipLaunchKernelGGL(real_to_cplx_kernel, dim3(gx, ns), 256, 0, st, patches, buf, per, c, ch, q);
+      int rc = dft3d(buf, ns, rd, rh, rw, 0, st);
+      if (rc) return rc;
+      if (pass == 0) {
+        hipLaunchKernelGGL(gibbs_mask_kernel, dim3(gx, ns), 256, 0, st, buf, rd, rh, rw, q);
+      } else {
+        hipLaunchKernelGGL(logabs_partial_kernel, dim3(chunks, ns), 256, 0, st, buf, per, chunks, q, part);
+        hipLaunchKernelGGL(spike_kernel, ns, 64, 0, st, buf, rd, rh, rw, chunks, part, q);
+      }
+      rc = dft3d(buf, ns, rd, rh, rw, 1, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(cplx_to_real_kernel, dim3(gx, ns), 256, 0, st, buf, patches, per, c, ch, q);
+    }
+  }
+  SEGMI_LAUNCH_CHECK("kspace_augment");
+  return SEGMI_OK;
+}
+
+}  // extern "C"

@@ -446,3 +446,33 @@ def intensity_augment(patches, contrast=None, hist=None, bias=None) -> None:
                                       arr(gam, np.float32), arr(hon, np.uint8), arr(ctl, np.float32),
                                       nctrl, arr(bon, np.uint8), arr(cof, np.float32), _ptr(ws),
                                       _stream()), "intensity_augment")
+
+
+def kspace_augment(patches, gibbs=None, spike=None) -> None:
+    """In-place RandGibbsNoise / RandKSpaceSpikeNoise on f32 NDHWC patches.
+
+    gibbs = (on uint8[n], alpha f32[n]); spike = (on uint8[n], loc int32[n][3] (z,y,x), u f32[n])."""
+    _require_device(patches)
+    if patches.dtype != torch.float32 or patches.dim() != 5 or not patches.is_contiguous():
+        raise ValueError("kspace_augment: dense float32 [n, d, h, w, c] patches expected")
+    n, rd, rh, rw, c = patches.shape
+    gon, alpha = gibbs if gibbs is not None else (None, None)
+    son, loc, u = spike if spike is not None else (None, None, None)
+    nsel = max(int(np.asarray(gon).astype(bool).sum()) if gon is not None else 0,
+               int(np.asarray(son).astype(bool).sum()) if son is not None else 0)
+    if nsel == 0:
+        return
+    ws = torch.empty(int(lib.segmi_kspace_workspace(n, rd, rh, rw)), dtype=torch.uint8,
+                     device=patches.device)
+    keep = []
+
+    def arr(x, dt):
+        if x is None:
+            return None
+        a = np.ascontiguousarray(np.asarray(x, dtype=dt))
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    check(lib.segmi_kspace_augment(_ptr(patches), n, rd, rh, rw, c, arr(gon, np.uint8),
+                                   arr(alpha, np.float32), arr(son, np.uint8), arr(loc, np.int32),
+                                   arr(u, np.float32), _ptr(ws), _stream()), "kspace_augment")

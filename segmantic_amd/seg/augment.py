@@ -10,21 +10,19 @@ MONAI's transforms do and composes the spatial ones into one index map:
   composed and applied inside the patch gather (one interpolation instead of up to four, no
   whole-volume passes; "area" zoom interpolation of the image is approximated by trilinear).
 * ``augment_intensity``: ``RandAdjustContrastd(prob=0.2, gamma=(0.5, 4.5))``,
-  ``RandHistogramShiftd(prob=0.2, num_control_points=10)``, ``RandBiasFieldd(prob=0.2)`` per patch.
-  ``RandGibbsNoised`` / ``RandKSpaceSpikeNoised`` (k-space transforms) are not implemented: a
-  warning is issued once and they are skipped.
+  ``RandHistogramShiftd(prob=0.2, num_control_points=10)``, ``RandBiasFieldd(prob=0.2)``,
+  ``RandGibbsNoised(prob=0.2, alpha=(0, 1))``, ``RandKSpaceSpikeNoised(prob=0.2)`` per patch (the
+  spike intensity's default range, 0.95..1.1 x 2.5 x mean log|K|, is evaluated on the device from a
+  host-drawn U(0,1)).
 
 Spatial axes: the cached volumes are [C, d0, d1, d2]; ``range_x`` rotates about d0, ``range_y``
 about d1, ``range_z`` about d2, as MONAI names the axes of a channel-first array.
 """
 from __future__ import annotations
 
-import warnings
 from typing import Optional, Tuple
 
 import numpy as np
-
-_warned = False
 
 
 def _rot(axis: int, angle: float) -> np.ndarray:
@@ -83,13 +81,9 @@ def forward_point(m_d012: np.ndarray, pt) -> np.ndarray:
     return (inv @ np.array([pt[0], pt[1], pt[2], 1.0]))[:3]
 
 
-def draw_intensity(rng: np.random.RandomState, n: int, warn_kspace: bool = True):
-    """Per-patch draws: (contrast, hist, bias) tuples for ``ops.intensity_augment``."""
-    global _warned
-    if warn_kspace and not _warned:
-        warnings.warn("segmantic_amd: RandGibbsNoised / RandKSpaceSpikeNoised of augment_intensity are "
-                      "not implemented on the GPU sampler and are skipped")
-        _warned = True
+def draw_intensity(rng: np.random.RandomState, n: int, roi=None):
+    """Per-patch draws: (contrast, hist, bias) for ``ops.intensity_augment`` and, when ``roi`` is
+    given, (gibbs, spike) for ``ops.kspace_augment``."""
     con = (rng.rand(n) < 0.2).astype(np.uint8)
     gam = rng.uniform(0.5, 4.5, n).astype(np.float32)
     hon = (rng.rand(n) < 0.2).astype(np.uint8)
@@ -99,4 +93,12 @@ def draw_intensity(rng: np.random.RandomState, n: int, warn_kspace: bool = True)
             ctrl[i, k] = rng.uniform(ctrl[i, k - 1], ctrl[i, k + 1])
     bon = (rng.rand(n) < 0.2).astype(np.uint8)
     coef = rng.uniform(0.0, 0.1, (n, 20)).astype(np.float32)
-    return (con, gam), (hon, ctrl.astype(np.float32)), (bon, coef)
+    out = ((con, gam), (hon, ctrl.astype(np.float32)), (bon, coef))
+    if roi is None:
+        return out
+    gon = (rng.rand(n) < 0.2).astype(np.uint8)
+    alpha = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    son = (rng.rand(n) < 0.2).astype(np.uint8)
+    loc = np.stack([rng.randint(0, int(r), n) for r in roi], 1).astype(np.int32)
+    u = rng.rand(n).astype(np.float32)
+    return out + ((gon, alpha), (son, loc, u))

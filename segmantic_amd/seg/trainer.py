@@ -107,8 +107,9 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
             ops.warp_crop_patches(src, it["label"][0].contiguous(), [[0] + s for s in starts], flips,
                                   to_index_map_xyz(spatial), out_i, out_l)
         if net.augment_intensity:
-            con, hist, bias = draw_intensity(rng, len(starts))
+            con, hist, bias, gibbs, spike = draw_intensity(rng, len(starts), roi)
             ops.intensity_augment(out_i, con, hist, bias)
+            ops.kspace_augment(out_i, gibbs, spike)
         imgs.append(out_i.permute(0, 4, 1, 2, 3))
         labs.append(out_l.unsqueeze(1))
     return {"image": torch.cat(imgs).contiguous(), "label": torch.cat(labs).contiguous()}

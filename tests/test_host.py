@@ -299,10 +299,9 @@ def test_augmentation_draws_follow_the_reference_distributions():
     assert abs(fired / 2000 - (1 - 0.8 ** 4)) < 0.04
     xyz = aug.to_index_map_xyz(np.arange(16, dtype=float).reshape(4, 4))
     assert xyz.shape == (3, 4) and xyz[0, 0] == 10 and xyz[2, 3] == 3 and xyz[0, 3] == 11
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        con, hist, bias = aug.draw_intensity(rng, 64)
+    con, hist, bias, gibbs, spike = aug.draw_intensity(rng, 64, (16, 24, 32))
+    assert gibbs[1].min() >= 0 and gibbs[1].max() <= 1 and spike[1].shape == (64, 3)
+    assert spike[1][:, 0].max() < 16 and spike[1][:, 1].max() < 24 and spike[1][:, 2].max() < 32
     assert hist[1].shape == (64, 10) and np.all(np.diff(hist[1], axis=1) >= 0)
     assert np.all(hist[1][:, 0] == 0) and np.all(hist[1][:, -1] == 1)
     assert bias[1].shape == (64, 20) and bias[1].min() >= 0 and bias[1].max() < 0.1

@@ -701,3 +701,40 @@ def test_intensity_augment_matches_numpy():
             coords = [np.linspace(-1, 1, d) for d in (rd, rh, rw)]
             v = v * np.exp(leggrid3d(coords[0], coords[1], coords[2], cm))
         assert np.abs(got[i] - v).max() < 2e-4 * max(1.0, np.abs(v).max()), i
+
+
+def test_kspace_augment_matches_numpy_fft():
+    """RandGibbsNoise / RandKSpaceSpikeNoise (monai_unet.py:209-210) against numpy.fft with the
+    reference's shift conventions; odd and non-power-of-two extents exercise the direct DFT."""
+    g = torch.Generator().manual_seed(13)
+    n, shp = 4, (6, 9, 10)
+    x = torch.randn((n,) + shp + (1,), generator=g)
+    xd = x.to(DEV).contiguous()
+    gon = np.array([1, 0, 1, 0], np.uint8); alpha = np.array([0.33, 0.52, 0.71, 0.1], np.float32)   # radii away from any bin distance
+    son = np.array([0, 1, 1, 0], np.uint8)
+    loc = np.array([[1, 2, 3], [5, 0, 9], [3, 4, 5], [0, 0, 0]], np.int32)
+    u = np.array([0.1, 0.6, 0.9, 0.5], np.float32)
+    ops.kspace_augment(xd, (gon, alpha), (son, loc, u))
+    torch.cuda.synchronize()
+    got = xd.cpu().numpy()[..., 0]
+    ax = (0, 1, 2)
+    for i in range(n):
+        v = x.numpy()[i, ..., 0].astype(np.float64)
+        if gon[i]:
+            k = np.fft.fftshift(np.fft.fftn(np.fft.ifftshift(v, axes=ax), axes=ax), axes=ax)
+            r = (1 - float(alpha[i])) * max(shp) * np.sqrt(2) / 2.0
+            ctr = (np.array(shp) - 1) / 2
+            zz, yy, xx = np.ogrid[0:shp[0], 0:shp[1], 0:shp[2]]
+            dist = np.sqrt((zz - ctr[0]) ** 2 + (yy - ctr[1]) ** 2 + (xx - ctr[2]) ** 2)
+            k = k * (dist <= r)
+            v = np.fft.fftshift(np.fft.ifftn(np.fft.ifftshift(k, axes=ax), axes=ax), axes=ax).real
+        if son[i]:
+            k = np.fft.fftshift(np.fft.fftn(np.fft.ifftshift(v, axes=ax), axes=ax), axes=ax)
+            log_abs = np.log(np.abs(k) + 1e-10)
+            phase = np.angle(k)
+            inten = log_abs.mean() * 2.5 * (0.95 + 0.15 * float(u[i]))
+            log_abs[tuple(loc[i])] = inten
+            k = np.exp(log_abs) * np.exp(1j * phase)
+            v = np.fft.fftshift(np.fft.ifftn(np.fft.ifftshift(k, axes=ax), axes=ax), axes=ax).real
+        assert np.abs(got[i] - v).max() < 5e-4 * max(1.0, np.abs(v).max()), i
+    assert np.array_equal(got[3], x.numpy()[3, ..., 0])          # untouched patch
