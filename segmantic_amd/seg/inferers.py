@@ -85,7 +85,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                              sigma_scale: float = 0.125, device=None,
                              return_labels: bool = False, window_dtype: torch.dtype = torch.float32,
                              window_range: Optional[Tuple[int, int]] = None,
-                             blend: str = "auto", return_logits: bool = True):
+                             blend: str = "auto", return_logits: bool = True,
+                             z_slab: Optional[Tuple[int, int]] = None):
     """inputs [B,C,D,H,W] float32 on the GPU.  ``predictor`` maps [b,C,*roi] -> [b,K,*roi].
 
     Returns logits [B,K,D,H,W] (float32), or a ``SlidingWindowResult`` when ``return_labels``
@@ -97,6 +98,12 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     "stream" read-modify-writes an f32 accumulator per window group (the reference's data flow);
     "auto" picks deferred when the cache fits in 60 % of the free HBM.  Both add the windows of a
     voxel in schedule order in f32, so their results are bit-identical.
+
+    ``z_slab`` = (z0, z1): compute only planes [z0, z1) of the first spatial dimension -- the
+    windows that intersect the slab are run (all of them, so every voxel of the slab gets its
+    complete ordered sum: the slab is bit-identical to the same planes of the full result).  This
+    is the multi-GPU form of one volume: rank r takes slab r of ``z_slabs`` and only the label
+    slabs travel (``gather_label_slabs``); needs the deferred blend.
     """
     if inputs.dim() != 5:
         raise ValueError("sliding_window_inference expects [B,C,D,H,W]")
@@ -116,9 +123,22 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     for starts in per_dim:
         wins = [w + (s,) for w in wins for s in starts]
     lo, hi = (0, len(wins)) if window_range is None else window_range
+    out_d, z_off = orig[0], 0
+    if z_slab is not None:
+        if window_range is not None or blend == "stream":
+            raise ValueError("z_slab needs the deferred blend and excludes window_range")
+        z_off, z1 = int(z_slab[0]), int(z_slab[1])
+        if not 0 <= z_off < z1 <= orig[0]:
+            raise ValueError(f"z_slab {z_slab} outside the volume depth {orig[0]}")
+        ks = [k for k, s0 in enumerate(per_dim[0]) if s0 - pad_lo[0] < z1 and s0 - pad_lo[0] + roi[0] > z_off]
+        nyx = len(per_dim[1]) * len(per_dim[2])
+        lo, hi = ks[0] * nyx, (ks[-1] + 1) * nyx
+        out_d = z1 - z_off
+        blend = "deferred"
     # window origins in un-padded image coordinates (the gather kernel zero-fills outside)
     wins_u = [tuple(s - p for s, p in zip(w, pad_lo)) for w in wins]
     per_dim_u = [[s - p for s in lst] for lst, p in zip(per_dim, pad_lo)]
+    per_dim_b = [[s - z_off for s in per_dim_u[0]], per_dim_u[1], per_dim_u[2]]   # blend coordinates
     img = inputs.float()
     img = img.view(B, orig[0], orig[1], orig[2], 1) if Cin == 1 and img.is_contiguous() else as_ndhwc(img)
     imp = None
@@ -164,13 +184,13 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                 ops.sw_scatter_add(pn, grp, acc, cnt, imp)
         lab = None
         if not partial and return_labels:
-            lab = torch.empty((orig[0], orig[1], orig[2]),
+            lab = torch.empty((out_d, orig[1], orig[2]),
                               dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)
         if deferred:
             if want_logits:
-                acc = torch.empty((1, orig[0], orig[1], orig[2], K), dtype=torch.float32, device=dev)
-            cnt = torch.empty((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
-            ops.sw_blend(cache, per_dim_u, lo, hi, roi, orig[0], orig[1], orig[2], importance=imp,
+                acc = torch.empty((1, out_d, orig[1], orig[2], K), dtype=torch.float32, device=dev)
+            cnt = torch.empty((out_d, orig[1], orig[2]), dtype=torch.float32, device=dev)
+            ops.sw_blend(cache, per_dim_b, lo, hi, roi, out_d, orig[1], orig[2], importance=imp,
                          out_logits=acc if want_logits else None, out_count=cnt, labels=lab,
                          normalize=not partial)
             cache = None
@@ -187,6 +207,33 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         return logits
     labels = None if labs[0] is None else torch.stack(labs).unsqueeze(1)
     return SlidingWindowResult(logits, labels, torch.stack(cnts))
+
+
+def z_slabs(depth: int, world: int) -> List[Tuple[int, int]]:
+    """`world` contiguous plane ranges covering [0, depth), sizes differing by at most one."""
+    base, rem = divmod(int(depth), int(world))
+    out, z = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((z, z + n))
+        z += n
+    return out
+
+
+def gather_label_slabs(labels_slab: torch.Tensor, depth: int, rank: int, world: int, group=None):
+    """All-gather the per-rank label slabs ([..., d_r, H, W], the slab of ``z_slabs(depth, world)[rank]``)
+    into the full label volume on every rank.  Labels are 1 byte per voxel: 128 MB for a 512^3
+    volume, against 8.6 GB for the f32 logits -- the only data-path exchange of sharded inference."""
+    import torch.distributed as dist
+    slabs = z_slabs(depth, world)
+    dmax = max(b - a for a, b in slabs)
+    lead = labels_slab.shape[:-3]
+    pad = torch.zeros(lead + (dmax,) + tuple(labels_slab.shape[-2:]), dtype=labels_slab.dtype,
+                      device=labels_slab.device)
+    pad[..., :labels_slab.shape[-3], :, :] = labels_slab
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[..., :b - a, :, :] for p, (a, b) in zip(parts, slabs)], dim=-3)
 
 
 class SlidingWindowInferer:

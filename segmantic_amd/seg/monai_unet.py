@@ -426,7 +426,16 @@ def predict(
     num_classes = net.num_classes
     net.freeze()
     net.eval()
-    device = make_device(gpu_ids)
+    # one process per GPU under torchrun: the volumes (independent objects) are dealt round-robin
+    # to the ranks, no data-path collective; rank 0 collects the per-volume scores at the end
+    rank, local_rank, world = env_world()
+    if world > 1:
+        init_distributed()
+        ids = list(gpu_ids) if gpu_ids else list(range(torch.cuda.device_count()))
+        device = torch.device(f"cuda:{ids[local_rank % len(ids)]}")
+        torch.cuda.set_device(device)
+    else:
+        device = make_device(gpu_ids)
     if device.type != "cuda":
         raise RuntimeError("segmantic_amd.predict needs an MI355X (no CPU execution path)")
     net.to(device)
@@ -453,6 +462,8 @@ def predict(
     class_dice_sum, class_dice_cnt = None, None
     with torch.no_grad():
         for i, img_path in enumerate(test_images):
+            if i % world != rank:
+                continue
             item = pipe.load(img_path, test_labels[i] if use_labels else None)
             val_pred = inferer(item["image"][None], net)             # [1,K,D,H,W] f32 logits
             label_vol = pipe.invert_and_discretize(val_pred[0], item)
@@ -470,6 +481,16 @@ def predict(
                 ok = (~np.isnan(dn[0])).astype(np.float64)
                 class_dice_sum = dz if class_dice_sum is None else class_dice_sum + dz
                 class_dice_cnt = ok if class_dice_cnt is None else class_dice_cnt + ok
+        if world > 1:
+            import torch.distributed as dist
+            parts = [None] * world
+            dist.all_gather_object(parts, (all_mean_dice, class_dice_sum, class_dice_cnt))
+            if rank != 0:
+                return
+            all_mean_dice = [v for p in parts for v in p[0]]
+            sums = [p[1] for p in parts if p[1] is not None]
+            class_dice_sum = sum(sums) if sums else None
+            class_dice_cnt = sum(p[2] for p in parts if p[2] is not None) if sums else None
         if output_dir is None:
             print("No output path specified, dice scores won't be saved.")
         else:
@@ -477,7 +498,9 @@ def predict(
                        all_mean_dice, delimiter=",")
         if use_labels:
             print("*" * 80)
-            print("Total Mean Dice: ", float(dice_metric.aggregate().item()))
+            total = float(dice_metric.aggregate().item()) if world == 1 else float(
+                np.nanmean(class_dice_sum / np.maximum(class_dice_cnt, 1)))
+            print("Total Mean Dice: ", total)
             print("Total Class Dice:")
             print_table(tissue_names[1:], class_dice_sum / np.maximum(class_dice_cnt, 1))
 

@@ -53,3 +53,30 @@ def test_gradsync_bucketed_allreduce_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _slab_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from segmantic_amd.seg.distributed import init_distributed
+    from segmantic_amd.seg.inferers import gather_label_slabs, z_slabs
+    init_distributed(backend="gloo")
+    depth = 5                                     # uneven: slabs (0,3) and (3,5)
+    full = (torch.arange(depth * 4 * 3) % 251).to(torch.uint8).reshape(1, 1, depth, 4, 3)
+    a, b = z_slabs(depth, world)[rank]
+    got = gather_label_slabs(full[:, :, a:b].clone(), depth, rank, world)
+    ret[rank] = bool(torch.equal(got, full))
+    dist.destroy_process_group()
+
+
+def test_sharded_inference_label_slab_gather_gloo_world2():
+    """Multi-GPU form of one sliding-window volume: ranks own z-slabs, only label slabs travel."""
+    from segmantic_amd.seg.inferers import z_slabs
+    assert z_slabs(512, 8) == [(64 * r, 64 * r + 64) for r in range(8)]
+    assert z_slabs(5, 2) == [(0, 3), (3, 5)] and z_slabs(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slab_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -112,6 +112,26 @@ def test_sliding_window_deferred_and_streaming_blends_are_bit_identical(mode, mi
     assert c.logits is None and torch.equal(c.labels, ba)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sliding_window_z_slabs_reproduce_the_full_volume_bit_for_bit(world):
+    """Sharded inference of one volume: every rank's slab (all windows that touch it, ordered
+    blend) equals the same planes of the unsharded result -- logits, counts and labels."""
+    from segmantic_amd.seg.inferers import z_slabs
+    _, net = pair(4, (16, 32, 64), (2, 2))
+    net.eval()
+    img, _ = synthetic_batch(1, 40, 4, seed=8)
+    img = img[..., :37, :36, :40].to(DEV)
+    with torch.no_grad():
+        full = sliding_window_inference(img, (16, 16, 16), 4, net, 0.5, "gaussian", return_labels=True,
+                                        blend="deferred")
+        fl, fc, fb = full.logits.clone(), full.count.clone(), full.labels.clone()
+        for a, b in z_slabs(37, world):
+            part = sliding_window_inference(img, (16, 16, 16), 4, net, 0.5, "gaussian",
+                                            return_labels=True, z_slab=(a, b))
+            assert torch.equal(part.logits, fl[:, :, a:b]) and torch.equal(part.count, fc[:, a:b])
+            assert torch.equal(part.labels, fb[:, :, a:b])
+
+
 def test_sliding_window_image_smaller_than_roi_and_inferer_class():
     ref, net = pair(2, (16, 32), (2,))
     ref.eval(); net.eval()
