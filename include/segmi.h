@@ -267,6 +267,21 @@ int segmi_kspace_augment(float* patches, int count, int rd, int rh, int rw, int 
                          const uint8_t* spike_on_host, const int32_t* spike_loc_host,
                          const float* spike_u_host, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------- model ensembles ------ */
+/* Combination of `models` (<= 16) predictions over n elements, monai_unet.py:848-1004.
+ * *_host arguments are HOST arrays (of device pointers / scalars).
+ *  mean  : MeanEnsembled with weights: out = mean_e(logits_e * w_e / mean(w)) (f32, n = K * voxels)
+ *  vote  : VoteEnsembled on int32 label volumes: most frequent label, ties -> smallest label
+ *  select: segmantic SelectBestEnsemble (seg/transforms.py:15-88): for each (tissue, model) pair in
+ *          order, out[labels[model] == tissue] = tissue; unclaimed voxels are 0. */
+int segmi_ensemble_mean(const float* const* logits_host, const float* weights_host, int models,
+                        int64_t n, float* out, void* stream);
+int segmi_ensemble_vote(const int32_t* const* labels_host, int models, int64_t n, int32_t* out,
+                        void* stream);
+int segmi_ensemble_select(const int32_t* const* labels_host, int models, const int32_t* tissue_host,
+                          const int32_t* model_host, int pairs, int64_t n, int32_t* out,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,12 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# PyTorch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  libsegmi.so is linked
+# against libamdhip64.so.7 by soname, so when torch's copy is already in the process the loader
+# binds libsegmi to THAT instance and both share one runtime (streams, device memory).  Loaded the
+# other way round the process ends up with two HIP runtimes and libsegmi's sees no device.
+import torch  # noqa: F401,E402
+
 SEGMI_F32 = 0
 SEGMI_BF16 = 1
 
@@ -85,6 +91,9 @@ SIGNATURES = {
     "segmi_warp_crop_patches": (_i, [_AP, _P, _P, _P, _i, _P, _i, _AP, _P, _P]),
     "segmi_intensity_workspace": (_i64, [_i]),
     "segmi_intensity_augment": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _i, _P, _P, _P, _P]),
+    "segmi_ensemble_mean": (_i, [_P, _P, _i, _i64, _P, _P]),
+    "segmi_ensemble_vote": (_i, [_P, _i, _i64, _P, _P]),
+    "segmi_ensemble_select": (_i, [_P, _i, _P, _P, _i, _i64, _P, _P]),
     "segmi_kspace_workspace": (_i64, [_i, _i, _i, _i]),
     "segmi_kspace_augment": (_i, [_P, _i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P]),
 }

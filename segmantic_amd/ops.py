@@ -476,3 +476,35 @@ def kspace_augment(patches, gibbs=None, spike=None) -> None:
     check(lib.segmi_kspace_augment(_ptr(patches), n, rd, rh, rw, c, arr(gon, np.uint8),
                                    arr(alpha, np.float32), arr(son, np.uint8), arr(loc, np.int32),
                                    arr(u, np.float32), _ptr(ws), _stream()), "kspace_augment")
+
+
+def _ptr_table(tensors, dtype):
+    for t in tensors:
+        _require_device(t)
+        if t.dtype != dtype or not t.is_contiguous():
+            raise ValueError(f"ensemble: contiguous {dtype} tensors expected")
+    tab = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return tab
+
+
+def ensemble_mean(logits, weights, out) -> None:
+    """out = mean_e(logits[e] * w[e] / mean(w)) over same-shaped f32 tensors (MONAI MeanEnsemble)."""
+    tab = _ptr_table(list(logits) + [out], torch.float32)
+    w = np.ascontiguousarray(np.asarray(weights, dtype=np.float32)) if weights is not None else None
+    check(lib.segmi_ensemble_mean(tab, w.ctypes.data_as(C.c_void_p) if w is not None else None,
+                                  len(logits), out.numel(), _ptr(out), _stream()), "ensemble_mean")
+
+
+def ensemble_vote(labels, out) -> None:
+    tab = _ptr_table(list(labels) + [out], torch.int32)
+    check(lib.segmi_ensemble_vote(tab, len(labels), out.numel(), _ptr(out), _stream()), "ensemble_vote")
+
+
+def ensemble_select(labels, tissue_model: dict, out) -> None:
+    """SelectBestEnsemble: tissue_model = {tissue id: model index}, applied in dict order."""
+    tab = _ptr_table(list(labels) + [out], torch.int32)
+    ts = np.ascontiguousarray(np.asarray(list(tissue_model.keys()), dtype=np.int32))
+    ms = np.ascontiguousarray(np.asarray(list(tissue_model.values()), dtype=np.int32))
+    check(lib.segmi_ensemble_select(tab, len(labels), ts.ctypes.data_as(C.c_void_p),
+                                    ms.ctypes.data_as(C.c_void_p), len(ts), out.numel(), _ptr(out),
+                                    _stream()), "ensemble_select")

@@ -511,3 +511,165 @@ def _argmax_labels(logits: torch.Tensor) -> torch.Tensor:
     lab = torch.empty(lg.shape[:4], dtype=torch.int32, device=lg.device)
     ops.argmax(lg, lab)
     return lab.unsqueeze(1)
+
+
+# =============================================================================================
+# cross validation / ensembles (reference ``:728-1004``): orchestration over train() / predict()
+# =============================================================================================
+def cross_validate(
+    image_dir: Path,
+    labels_dir: Path,
+    tissue_list: Path,
+    output_dir: Path,
+    config_files_dir: Path,
+    test_image_dir: Path = None,
+    test_labels_dir: Path = None,
+    num_splits: int = 7,
+    gpu_ids: List[int] = [0],
+):
+    """reference ``:728-831``: k-fold data lists, one ``train-config`` run per (config file, fold)
+    in its own process, optional generalisation test of every checkpoint of the fold.
+
+    Two defects of the reference loop are not reproduced: the training subprocess is started with
+    an argument list AND ``shell=True`` (which drops the arguments on POSIX), and the test images
+    are globbed with ``".nii.gz"`` (matches nothing) instead of ``"*.nii.gz"``."""
+    import subprocess as sp
+    import sys
+    from functools import partial
+
+    from ..utils import config
+    from .dataset import PairedDataSet
+
+    print("Cross-validating")
+    output_dir = Path(output_dir)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    tissue_dict = load_tissue_list(tissue_list)
+    print(tissue_dict)
+    data_dicts = PairedDataSet.create_data_dict(image_dir=image_dir, labels_dir=labels_dir)
+    test_data_dicts = []
+    if test_image_dir and test_labels_dir:
+        test_data_dicts = PairedDataSet.create_data_dict(image_dir=test_image_dir, labels_dir=test_labels_dir)
+    all_datafold_paths = PairedDataSet.kfold_crossval(
+        num_splits=num_splits, data_dicts=data_dicts, output_dir=output_dir / "datafolds",
+        test_data_dicts=test_data_dicts)
+    for config_file in sorted(Path(config_files_dir).iterdir()):
+        assert config_file.suffix in [".json", ".yml"], f"suffix: {config_file}"
+        is_json = config_file.suffix.lower() == ".json"
+        dumps = partial(config.dumps, is_json=is_json)
+        loads = partial(config.loads, is_json=is_json)
+        output_dir_scenario = output_dir / config_file.name.rsplit(".", 1)[0]
+        output_dir_scenario.mkdir(exist_ok=True)
+        for count, dataset_path in enumerate(all_datafold_paths):
+            current_output = output_dir_scenario / str(count)
+            print(current_output)
+            current_output.mkdir(exist_ok=True)
+            data: dict = loads(config_file.read_text())
+            data["datalist"] = str(dataset_path)
+            data.pop("image_dir", None)
+            data.pop("labels_dir", None)
+            data["output_dir"] = str(current_output)
+            current_config = current_output / ("config.json" if is_json else "config.yml")
+            current_config.write_text(dumps(data))
+            print("start training")
+            env = dict(os.environ)    # the package may be used from a source tree (not installed)
+            env["PYTHONPATH"] = os.pathsep.join(
+                [str(Path(__file__).resolve().parents[2])] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+            result = sp.run([sys.executable, "-m", "segmantic_amd.commands.monai_unet_cli", "train-config",
+                             "-c", str(current_config)], cwd=os.fspath(current_output), env=env)
+            print(f"training finished : {result.returncode == 0}")
+            if test_image_dir is not None and test_labels_dir is not None:
+                test_image_dir, test_labels_dir = Path(test_image_dir), Path(test_labels_dir)
+                assert test_image_dir.is_dir() and test_labels_dir.is_dir()
+                test_images = sorted(test_image_dir.glob("*.nii.gz"))
+                test_labels = sorted(test_labels_dir.glob("*.nii.gz"))
+                assert len(test_images) == len(test_labels)
+                for file in sorted(current_output.iterdir()):
+                    if file.match("*.ckpt"):
+                        print("start prediction")
+                        predict(model_file=file, output_dir=current_output, test_images=test_images,
+                                test_labels=test_labels, tissue_dict=tissue_dict, dropout=0.0,
+                                spacing=[1, 1, 1], gpu_ids=gpu_ids)
+
+
+def _one_hot_logits(labels: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """[D,H,W] int32 labels -> [K,D,H,W] f32 one-hot (so the label volume can take the same
+    inverse chain as logits: trilinear in class-probability space, then argmax)."""
+    out = torch.zeros((num_classes,) + tuple(labels.shape), dtype=torch.float32, device=labels.device)
+    out.scatter_(0, labels.long().clamp_(0, num_classes - 1)[None], 1.0)
+    return out
+
+
+def ensemble_creator(
+    model_files: List[Path],
+    test_images: List[Path],
+    test_labels: Optional[List[Path]] = None,
+    output_dir: Path = None,
+    tissue_dict: Dict[str, int] = None,
+    spacing: Sequence[float] = [],
+    combination_mode="select_best",
+    candidate_per_tissue_path: Optional[Path] = None,
+    gpu_ids: List[int] = [],
+):
+    """reference ``:848-1004``: every model predicts each volume with sliding windows of 96^3 at
+    overlap 0.5 (``:840-842``); the predictions are combined on the device (``csrc/ensemble.hip``):
+    ``mean`` (logits weighted by the ``val_dice`` in the checkpoint file name), ``vote`` (majority
+    of the per-model arg-max labels) or ``select_best`` (per tissue, the labels of the model named
+    in ``candidate_per_tissue_path``); the result is carried back through the inverse
+    pre-processing and saved as ``<stem>.nii.gz``."""
+    from ..utils import config
+    from .pipeline import PredictPipeline
+
+    mode = getattr(combination_mode, "value", combination_mode)
+    if mode not in ("mean", "vote", "select_best"):
+        raise ValueError(f"unknown combination mode {combination_mode}")
+    if mode == "select_best":
+        if candidate_per_tissue_path is None:
+            raise ValueError("When using the 'select_best'-mode, candidate_per_tissue_path needs to be specified.")
+        if tissue_dict is None:
+            raise RuntimeError("'select_best' mode requires a tissue list")
+    if not model_files:
+        raise ValueError("ensemble_creator needs at least one checkpoint")
+    device = make_device(gpu_ids)
+    if device.type != "cuda":
+        raise RuntimeError("segmantic_amd.ensemble_creator needs an MI355X (no CPU execution path)")
+    models = [Net.load_from_checkpoint(str(p)) for p in model_files]
+    for m in models:
+        m.freeze()
+        m.eval()
+        m.to(device)
+    num_classes = models[0].num_classes
+    use_labels = bool(test_labels) and len(test_images) == len(test_labels)
+    pipe = PredictPipeline(device=device, spacing=spacing, with_label=use_labels)
+    if output_dir:
+        os.makedirs(output_dir, exist_ok=True)
+        output_dir = Path(output_dir)
+    inferer = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5)
+    weights = None
+    label_model = None
+    if mode == "mean":   # validation metric of each checkpoint as its weight (reference :924-927)
+        weights = [float(Path(p).stem.split("-")[-1].split("=")[1]) for p in model_files]
+    if mode == "select_best":
+        name_model = config.load(config_file=Path(candidate_per_tissue_path))
+        label_model = {int(tissue_dict[name]): int(idx) for name, idx in name_model.items()}
+    saved = []
+    with torch.no_grad():
+        for i, img_path in enumerate(test_images):
+            item = pipe.load(img_path, test_labels[i] if use_labels else None)
+            x = item["image"][None]
+            if mode == "mean":
+                outs = [inferer(x, m).contiguous().clone() for m in models]      # [1,K,D,H,W] views
+                comb = torch.empty_like(outs[0])
+                ops.ensemble_mean(outs, weights, comb)
+                combined = comb[0]
+            else:
+                labs = [_argmax_labels(inferer(x, m))[0, 0].contiguous() for m in models]
+                out = torch.empty_like(labs[0])
+                if mode == "vote":
+                    ops.ensemble_vote(labs, out)
+                else:
+                    ops.ensemble_select(labs, label_model, out)
+                combined = _one_hot_logits(out, num_classes)
+            label_vol = pipe.invert_and_discretize(combined, item)
+            if output_dir:
+                saved.append(pipe.save(label_vol, item, output_dir))
+    return saved

@@ -280,3 +280,46 @@ def test_training_with_spatial_and_intensity_augmentation(tmp_path):
             assert bool(torch.isfinite(b["image"]).all())
             lab = b["label"].cpu()
             assert bool((lab == lab.round()).all()) and 0 <= float(lab.min()) and float(lab.max()) <= 2
+
+
+def test_cross_validate_and_ensemble_predict(tmp_path):
+    """`cross-validate` (k-fold data lists, one training process per fold) and `ensemble-predict`
+    (mean / vote / select_best) of the reference CLI on the GPU path."""
+    import yaml
+    from typer.testing import CliRunner
+
+    from segmantic_amd.commands.monai_unet_cli import app
+    from segmantic_amd.data.nifti import read_nifti
+    datalist = _write_dataset(tmp_path / "data")
+    img_dir, lab_dir = tmp_path / "data" / "image", tmp_path / "data" / "label"
+    tissue = tmp_path / "labels.txt"
+    tissue.write_text("V7\nN2\nC1.00 0.00 0.00 0.50 A\nC0.00 1.00 0.00 0.50 B\n")
+    cfg_dir = tmp_path / "config_files"
+    cfg_dir.mkdir()
+    (cfg_dir / "plain.yml").write_text(yaml.safe_dump({
+        "spatial_size": [16, 16, 16], "channels": [16, 32, 64], "strides": [2, 2], "max_epochs": 1,
+        "mixed_precision": False, "num_samples": 2, "gpu_ids": [0], "tissue_list": str(tissue)}))
+    out = tmp_path / "cv"
+    cv = {"image_dir": str(img_dir), "labels_dir": str(lab_dir), "tissue_list": str(tissue),
+          "output_dir": str(out), "config_files_dir": str(cfg_dir), "num_splits": 2, "gpu_ids": [0]}
+    (tmp_path / "cv.yml").write_text(yaml.safe_dump(cv))
+    runner = CliRunner()
+    res = runner.invoke(app, ["cross-validate", "-c", str(tmp_path / "cv.yml")])
+    assert res.exit_code == 0, (res.output, res.exception)
+    folds = sorted((out / "datafolds").glob("fold_*.json"))
+    assert len(folds) == 2
+    ckpts = sorted((out / "plain").glob("*/epoch=*-val_loss=*-val_dice=*.ckpt"))
+    assert len(ckpts) >= 2                                      # one per fold at least
+    models = tmp_path / "models"
+    models.mkdir()
+    for c in ckpts[:2]:
+        (models / c.name.replace("epoch=0", f"epoch={c.parent.name}")).write_bytes(c.read_bytes())
+    cand = tmp_path / "best.yml"
+    cand.write_text(yaml.safe_dump({"A": 0, "B": 1}))
+    for mode, extra in (("mean", []), ("vote", []), ("select_best", ["-cy", str(cand)])):
+        rd = tmp_path / f"ens_{mode}"
+        res = runner.invoke(app, ["ensemble-predict", "-d", str(datalist.parent / "predict.json"), "-m", str(models),
+                                  "-t", str(tissue), "-r", str(rd), "-cm", mode, "--gpu-ids", "0"] + extra)
+        assert res.exit_code == 0, (mode, res.output, res.exception)
+        pred, _ = read_nifti(rd / "c3.nii.gz")
+        assert pred.shape == (24, 24, 24) and pred.max() <= 2

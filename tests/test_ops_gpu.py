@@ -738,3 +738,31 @@ def test_kspace_augment_matches_numpy_fft():
             v = np.fft.fftshift(np.fft.ifftn(np.fft.ifftshift(k, axes=ax), axes=ax), axes=ax).real
         assert np.abs(got[i] - v).max() < 5e-4 * max(1.0, np.abs(v).max()), i
     assert np.array_equal(got[3], x.numpy()[3, ..., 0])          # untouched patch
+
+
+def test_ensemble_kernels_match_monai_semantics():
+    """MeanEnsemble with weights, VoteEnsemble (ties -> smallest label), SelectBestEnsemble."""
+    g = torch.Generator().manual_seed(21)
+    E, K, n = 3, 5, 4097
+    logits = [torch.randn((1, K, n), generator=g) for _ in range(E)]
+    w = [0.81, 0.9, 0.42]
+    out = torch.empty((1, K, n), device=DEV)
+    ops.ensemble_mean([t.to(DEV) for t in logits], w, out)
+    st = torch.stack(logits)
+    wt = torch.tensor(w).view(E, 1, 1, 1)
+    ref = (st * wt / wt.mean(0, keepdim=True)).mean(0)
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 1e-5
+    labs = [torch.randint(0, K, (n,), generator=g, dtype=torch.int32) for _ in range(E)]
+    lo = torch.empty((n,), dtype=torch.int32, device=DEV)
+    ops.ensemble_vote([t.to(DEV) for t in labs], lo)
+    oh = torch.stack([torch.nn.functional.one_hot(t.long(), K).float() for t in labs]).mean(0)
+    torch.cuda.synchronize()
+    assert torch.equal(lo.cpu().long(), oh.argmax(1))
+    sel = {1: 2, 3: 0, 4: 1, 2: 0}                       # tissue -> model, applied in this order
+    ops.ensemble_select([t.to(DEV) for t in labs], sel, lo)
+    ref = torch.zeros((n,), dtype=torch.int32)
+    for tissue, model in sel.items():
+        ref[labs[model] == tissue] = tissue
+    torch.cuda.synchronize()
+    assert torch.equal(lo.cpu(), ref)
