@@ -105,8 +105,19 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     is the multi-GPU form of one volume: rank r takes slab r of ``z_slabs`` and only the label
     slabs travel (``gather_label_slabs``); needs the deferred blend.
     """
+    if inputs.dim() == 4:          # 2-D images: run as depth-1 volumes through the same kernels
+        own = hasattr(getattr(predictor, "__self__", predictor), "forward_into")
+        pred3 = predictor if own else (lambda w: predictor(w.squeeze(2)).unsqueeze(2))
+        res = sliding_window_inference(
+            inputs.unsqueeze(2), (1,) + tuple(roi_size), sw_batch_size, pred3, overlap, mode,
+            sigma_scale, device, return_labels, window_dtype, window_range, blend, return_logits, None)
+        if not return_labels:
+            return res.squeeze(2)
+        return SlidingWindowResult(None if res.logits is None else res.logits.squeeze(2),
+                                   None if res.labels is None else res.labels.squeeze(2),
+                                   res.count.squeeze(1))
     if inputs.dim() != 5:
-        raise ValueError("sliding_window_inference expects [B,C,D,H,W]")
+        raise ValueError("sliding_window_inference expects [B,C,D,H,W] (or [B,C,H,W])")
     if not inputs.is_cuda:
         raise RuntimeError("segmantic_amd sliding-window inference runs on the GPU only")
     if not 0 <= overlap < 1:

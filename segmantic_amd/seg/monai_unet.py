@@ -47,11 +47,13 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, net):
         ctx.net = net
-        return net._engine_for(x).forward(x, train=True).permute(0, 4, 1, 2, 3)
+        return net._to_reference_layout(net._engine_for(x).forward(x, train=True), x)
 
     @staticmethod
     def backward(ctx, g):
         eng = ctx.net._engine
+        if g.dim() == 4:                       # 2-D network called with [N, C, H, W]
+            g = g.unsqueeze(2)
         gd = as_ndhwc(g)
         if gd.dtype != eng.dtype:
             gd = gd.to(eng.dtype)
@@ -156,7 +158,14 @@ class Net(torch.nn.Module):
         with torch.cuda.device(eng.device):
             if self.training and torch.is_grad_enabled():
                 return _UNetFn.apply(x, self._anchor, self)
-            return eng.forward(x, train=self.training).permute(0, 4, 1, 2, 3)
+            return self._to_reference_layout(eng.forward(x, train=self.training), x)
+
+    @staticmethod
+    def _to_reference_layout(logits_ndhwc: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """NDHWC storage -> logical [N, K, D, H, W]; [N, K, H, W] when a 2-D network was given
+        a 4-D input."""
+        out = logits_ndhwc.permute(0, 4, 1, 2, 3)
+        return out.squeeze(2) if x.dim() == 4 else out
 
     def forward_into(self, x: torch.Tensor, out_ndhwc: torch.Tensor) -> bool:
         """Inference forward straight into a caller-owned NDHWC [B, D, H, W, K] buffer of the

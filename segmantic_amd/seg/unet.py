@@ -253,10 +253,8 @@ class UNetEngine:
     momentum = 0.1
 
     def __init__(self, params: UNetParams, device: torch.device, dtype: torch.dtype):
-        if params.dimensions != 3:
-            raise NotImplementedError(
-                "segmantic_amd: the HIP path implements spatial_dims=3 (2-D is on the roadmap, "
-                "SURVEY.md section 8f N4)")
+        if params.dimensions not in (2, 3):
+            raise NotImplementedError("segmantic_amd: spatial_dims must be 2 or 3")
         if dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("compute dtype must be float32 or bfloat16")
         if any(s not in (1, 2) for s in params.strides):
@@ -279,22 +277,30 @@ class UNetEngine:
     # ------------------------------------------------------------------ arenas
     def _build_arena(self):
         named = list(self.net.named_parameters())
-        total = sum(p.numel() for _, p in named)
+        total = sum(int(math.prod(self._arena_shape(p))) for _, p in named)
         self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         self._pviews: Dict[str, torch.Tensor] = {}
         self._gviews: Dict[str, torch.Tensor] = {}
         self.param_offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
+        self._palias: Dict[str, torch.Tensor] = {}
         for name, p in named:
-            n = p.numel()
-            view = self.flat[off:off + n].view(p.shape)
-            view.copy_(p.data.to(self.device, torch.float32))
-            p.data = view                      # nn.Parameter now aliases the arena
-            g = self.flat_grad[off:off + n].view(p.shape)
-            p.grad = g
+            shape = self._arena_shape(p)
+            n = int(math.prod(shape))
+            view = self.flat[off:off + n].view(shape)
+            g = self.flat_grad[off:off + n].view(shape)
+            alias, galias = view, g
+            if len(shape) != p.dim():          # 2-D kernel embedded in the kd = centre plane
+                view.zero_()
+                mid = shape[2] // 2
+                alias, galias = view[:, :, mid], g[:, :, mid]
+            alias.copy_(p.data.to(self.device, torch.float32))
+            p.data = alias                     # nn.Parameter now aliases the arena
+            p.grad = galias
             self._pviews[name] = view
             self._gviews[name] = g
+            self._palias[name] = alias
             self.param_offsets[name] = (off, n)
             off += n
         self._bviews: Dict[str, torch.Tensor] = {}
@@ -311,14 +317,25 @@ class UNetEngine:
             self._bviews[name] = b.data
         self.num_params = total
 
+    def _arena_shape(self, p) -> tuple:
+        """Shape a parameter takes in the arena.  spatial_dims=2: a [Co, Ci, k, k] kernel lives in
+        the centre plane of a [Co, Ci, k, k, k] one (zeros elsewhere) so the 3-D kernels compute the
+        2-D convolution on a depth-1 volume: the off-centre taps only ever meet the zero padding,
+        their weights and gradients stay exactly 0, and the nn.Parameter / checkpoint keep MONAI's
+        2-D shape (a strided view of the centre plane)."""
+        if self.net.dimensions == 2 and p.dim() == 4:
+            return tuple(p.shape[:2]) + (p.shape[2],) + tuple(p.shape[2:])
+        return tuple(p.shape)
+
     def rebind(self):
         """Re-alias parameters after an external ``.to()`` / ``load_state_dict`` replaced data."""
         for name, p in self.net.named_parameters():
-            view = self._pviews[name]
-            if p.data.data_ptr() != view.data_ptr():
-                view.copy_(p.data.to(self.device, torch.float32))
-                p.data = view
-            p.grad = self._gviews[name]
+            alias = self._palias[name]
+            if p.data.data_ptr() != alias.data_ptr():
+                alias.copy_(p.data.to(self.device, torch.float32))
+                p.data = alias
+            gv = self._gviews[name]
+            p.grad = gv if gv.dim() == p.dim() else gv[:, :, gv.shape[2] // 2]
         for name, b in self.net.named_buffers():
             tgt = self._bviews[name]
             if b.data.data_ptr() != tgt.data_ptr():
@@ -670,13 +687,17 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ public API
     def _prep_input(self, x: torch.Tensor) -> torch.Tensor:
-        """x: [N, C, D, H, W] float32 (reference layout) -> NDHWC compute-dtype tensor."""
-        if x.dim() != 5 or x.shape[1] != self.net.in_channels:
-            raise ValueError(f"expected input [N,{self.net.in_channels},D,H,W], got {tuple(x.shape)}")
+        """x: [N, C, D, H, W] float32 (reference layout; [N, C, H, W] or depth 1 for a 2-D
+        network) -> NDHWC compute-dtype tensor."""
+        if self.net.dimensions == 2 and x.dim() == 4:
+            x = x.unsqueeze(2)
+        if x.dim() != 5 or x.shape[1] != self.net.in_channels or (self.net.dimensions == 2 and x.shape[2] != 1):
+            raise ValueError(f"expected input [N,{self.net.in_channels},"
+                             f"{'D,' if self.net.dimensions == 3 else ''}H,W], got {tuple(x.shape)}")
         total_stride = 1
         for s in self.net.strides[:len(self.net.channels) - 1]:
             total_stride *= s
-        for s in x.shape[2:]:
+        for s in x.shape[(3 if self.net.dimensions == 2 else 2):]:
             if s % total_stride != 0:
                 # the reference fails here too (torch.cat of mismatching skip tensors)
                 raise ValueError(f"spatial extent {s} is not divisible by the network's total "

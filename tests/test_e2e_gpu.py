@@ -323,3 +323,43 @@ def test_cross_validate_and_ensemble_predict(tmp_path):
         assert res.exit_code == 0, (mode, res.output, res.exception)
         pred, _ = read_nifti(rd / "c3.nii.gz")
         assert pred.shape == (24, 24, 24) and pred.max() <= 2
+
+
+def test_spatial_dims_2_matches_oracle_and_trains():
+    """2-D UNet (reference tests/seg/test_unet.py:15-20 builds one): the 2-D kernels are the 3-D
+    ones on a depth-1 volume with the [k,k] weights in the centre plane of [k,k,k]."""
+    ref = deterministic_fill_(RefUNet(2, 1, 3, (16, 32, 64), (2, 2)), 0)
+    net = Net(num_classes=3, num_channels=1, spatial_dims=2, channels=(16, 32, 64), strides=(2, 2))
+    net.load_state_dict({"_model." + k: v.clone() for k, v in ref.state_dict().items()})
+    net.to(DEV)
+    assert net.spatial_dims == 2
+    assert tuple(dict(net._model.named_parameters())["model.0.conv.unit0.conv.weight"].shape) == (16, 1, 3, 3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((4, 1, 32, 48), generator=g)
+    lab = torch.randint(0, 3, (4, 1, 32, 48), generator=g).float()
+    ref.train(); net.train()
+    y_ref = ref(x)
+    loss_ref = ref_dice_loss(y_ref, lab)
+    loss_ref.backward()
+    res = net.training_step({"image": x.to(DEV), "label": lab.to(DEV)})
+    torch.cuda.synchronize()
+    y = net._engine._bufs["logits.t"].float().cpu().permute(0, 4, 1, 2, 3).squeeze(2)
+    assert float((y - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 2e-4
+    assert abs(float(res["loss"].cpu()) - float(loss_ref)) < 1e-4 * float(loss_ref)
+    # gradients landed in the 2-D views (centre plane of the embedded kernels); off-centre taps stay 0
+    sd_ref = dict(ref.named_parameters())
+    for key in ("model.0.conv.unit0.conv.weight", "model.2.0.conv.weight", "model.1.submodule.1.submodule.residual.weight"):
+        gw = net._engine._gviews[key]
+        g2 = gw if gw.dim() == 4 else gw[:, :, gw.shape[2] // 2]
+        gr = sd_ref[key].grad
+        assert float((g2.cpu() - gr).abs().max()) < 2e-3 * float(gr.abs().max()) + 1e-7, key
+        if gw.dim() == 5 and gw.shape[2] == 3:
+            assert float(gw[:, :, 0].abs().max()) == 0.0 and float(gw[:, :, 2].abs().max()) == 0.0
+    # eval + 2-D sliding window + checkpoint shapes
+    net.eval(); ref.eval()
+    with torch.no_grad():
+        ye = net(x.to(DEV)).float().cpu()
+        assert ye.shape == (4, 3, 32, 48)
+        sw = sliding_window_inference(x[:1].to(DEV), (16, 16), 4, net, 0.5, return_labels=True)
+        assert sw.logits.shape == (1, 3, 32, 48) and sw.labels.shape == (1, 1, 32, 48)
+    assert tuple(net.state_dict()["_model.model.0.conv.unit0.conv.weight"].shape) == (16, 1, 3, 3)
