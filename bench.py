@@ -182,7 +182,7 @@ def main():
         def run():
             with torch.no_grad():
                 return sliding_window_inference(vol, (args.size,) * 3, 4, net, overlap=args.overlap,
-                                                return_labels=True, window_dtype=torch.float32)
+                                                return_labels=True)
         for _ in range(args.warmup):
             run()
         eng = net._engine

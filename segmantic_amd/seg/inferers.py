@@ -83,7 +83,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                              predictor: Callable[[torch.Tensor], torch.Tensor],
                              overlap: float = 0.25, mode: str = "constant",
                              sigma_scale: float = 0.125, device=None,
-                             return_labels: bool = False, window_dtype: torch.dtype = torch.float32,
+                             return_labels: bool = False, window_dtype: Optional[torch.dtype] = None,
                              window_range: Optional[Tuple[int, int]] = None,
                              blend: str = "auto", return_logits: bool = True,
                              z_slab: Optional[Tuple[int, int]] = None):
@@ -158,7 +158,10 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     elif mode != "constant":
         raise ValueError(f"unsupported blend mode {mode}")
     dev = inputs.device
-    into = getattr(getattr(predictor, "__self__", predictor), "forward_into", None)
+    owner = getattr(predictor, "__self__", predictor)
+    into = getattr(owner, "forward_into", None)
+    if window_dtype is None:    # windows in the network's compute dtype: no separate cast pass
+        window_dtype = getattr(owner, "compute_dtype", None) or torch.float32
     partial = window_range is not None
     want_logits = return_logits or not return_labels or partial
     nvox_roi = roi[0] * roi[1] * roi[2]

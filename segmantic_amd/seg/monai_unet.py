@@ -234,7 +234,7 @@ class Net(torch.nn.Module):
         self.eval()
         with torch.no_grad():
             res = sliding_window_inference(images.to(self.device), roi_size, 4, self.forward,
-                                           return_labels=True, window_dtype=torch.float32)
+                                           return_labels=True)
             loss = self.loss_function(res.logits, labels)
             d = self.dice_metric(res.labels, labels.to(self.device).long())
         self.train(was)

@@ -705,6 +705,8 @@ class UNetEngine:
         x = x.to(self.device)
         n, c, d, h, w = x.shape
         xin = self._buf("input", (n, d, h, w, c))
+        if c == 1 and x.dtype == self.dtype and x.is_contiguous():
+            return x.view(n, d, h, w, 1)       # already NDHWC in the compute dtype (e.g. bf16 windows)
         if c == 1 and x.dtype == torch.float32 and x.is_contiguous():
             src = x.view(n, d, h, w, 1)
             if self.dtype == torch.float32:
