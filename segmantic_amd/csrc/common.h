@@ -117,7 +117,8 @@ template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
 // also waits for the previous block's global store, serialising an epilogue's stores on the
 // full memory round trip.  Touching the value once, unconditionally, removes all those waits.
 template <typename V> __device__ __forceinline__ void touch_v(V& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void touch_s(float& v) { asm volatile("" : "+s"(v)); }
+// scalar variant for wave-uniform values; "+v" because hipcc may already hold them in a VGPR
+__device__ __forceinline__ void touch_s(float& v) { asm volatile("" : "+v"(v)); }
 
 // sum over the 16 lanes that share (lane>>4): result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {

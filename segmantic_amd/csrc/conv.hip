@@ -17,8 +17,9 @@ int bn_stats_rows_for(const segmi_act* x);
 int stats_reserve_rows();
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
-                   const float* bias, const float* alpha, const segmi_act* res, int stride,
-                   hipStream_t st);
+                   const float* bias, const float* alpha, const segmi_act* res, float* stats,
+                   int stride, hipStream_t st);
+int conv_small_fwd_rows(const segmi_act* out);
 
 struct DirectParams {
   const void* in;
@@ -127,6 +128,13 @@ static inline int out_extent(int in, int ks, int stride) {
 
 using namespace segmi;
 
+// the first-layer kernel (conv_small.hip) takes the layer: shared by the launch and the rows query
+static inline bool small_fwd_eligible(int dtype, const segmi_act* in, const segmi_act* out, int ksize) {
+  const int es = dtype_size(dtype);
+  return conv_small_ok(in->c, out->c, ksize) && out->ld % 4 == 0 &&
+         ((uintptr_t)out->data % (4 * es)) == 0;
+}
+
 extern "C" {
 
 int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
@@ -138,6 +146,7 @@ int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out
     if (conv_ks_ok(dtype, in->c, ksize, stride)) return conv_ks_rows(out) + stats_reserve_rows();
     return conv_mfma_rows(out, stride) + stats_reserve_rows();
   }
+  if (small_fwd_eligible(dtype, in, out, ksize)) return conv_small_fwd_rows(out) + stats_reserve_rows();
   return bn_stats_rows_for(out) + stats_reserve_rows();
 }
 
@@ -183,15 +192,14 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
   }
   SEGMI_CHECK_ARG(w_src, "conv3d: direct path (channels not multiples of 16) needs w_src");
   SEGMI_CHECK_ARG(w_kind == 0 || w_kind == 1, "conv3d: bad w_kind %d", w_kind);
-  if (conv_small_ok(in->c, out->c, ksize) && w_kind == 0 && out->ld % 4 == 0 &&
-      ((uintptr_t)out->data % (4 * es)) == 0 &&
+  SEGMI_CHECK_ARG(!(stats_partials && small_fwd_eligible(dtype, in, out, ksize) && w_kind != 0),
+                  "conv3d: fused statistics on a small-Cin layer need the forward weight kind");
+  if (small_fwd_eligible(dtype, in, out, ksize) && w_kind == 0 &&
       (!residual || (residual->ld % 4 == 0 && ((uintptr_t)residual->data % (4 * es)) == 0))) {
     SEGMI_CHECK_ARG(!stats_partials || (!prelu_alpha && !residual),
                     "conv3d: fused statistics are taken before PReLU/residual");
-    const int rc = conv_small_fwd(dtype, in, out, w_src, bias, prelu_alpha, residual, stride, st);
-    if (rc) return rc;
-    if (stats_partials) return bn_stats_launch(dtype, out, stats_partials, st);
-    return SEGMI_OK;
+    return conv_small_fwd(dtype, in, out, w_src, bias, prelu_alpha, residual, stats_partials, stride,
+                          st);
   }
   DirectParams p{};
   p.in = in->data; p.out = out->data; p.w = w_src; p.bias = bias; p.alpha = prelu_alpha;

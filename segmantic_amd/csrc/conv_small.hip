@@ -1,8 +1,9 @@
 // conv_small.hip -- k3 convolutions with a tiny input-channel count (the network's first layer:
 // Cin = num_channels = 1..4, Cout = 16 or 32).  K = 27*Cin is too short for the MFMA path and
-// the layer is HBM-bound anyway (reads 1 voxel, writes 16 channels), so these are VALU kernels:
-//   forward : one thread per output voxel, all COUT channels in registers, weights through the
-//             scalar cache, 16-byte coalesced NDHWC stores.
+// the layer is HBM-bound (reads 1 voxel, writes 16 channels):
+//   forward : MFMA with k = (ci, tap) gathered element-wise from the staged halo tile (K = 27 is
+//             ONE 16x16x32 bf16 MFMA per 16 voxels x 16 channels), fused bias / statistics / PReLU
+//             / residual epilogue.
 //   wgrad   : MFMA with the voxel axis as K and (ci, tap) as N (see conv_small_wgrad_kernel);
 //             persistent workgroups, per-workgroup partial slabs (deterministic).
 #include "common.h"
@@ -12,67 +13,199 @@ namespace segmi {
 struct SmallConvParams {
   const void* in;
   void* out;
-  const float* w;     // torch layout [COUT][Cin][27]
+  const float* w;     // torch layout [Cout][Cin][27]
   const float* bias;
   const float* alpha;  // PReLU slope (nullable)
   const void* res;     // residual view (nullable), added after the activation
-  int N, Di, Hi, Wi, Do, Ho, Wo, Cin, ldi, ldo, ldr, stride;
+  float* stats;        // per-workgroup partial sums [grid.x][2][Cout] (nullable)
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cout, ldi, ldo, ldr;
+  int tz, ty, tx;
 };
 
-template <typename T, int COUT>
+// MFMA forward for tiny Cin:  D[co][vox] += W[co][k] * X[k][vox] with k = ci*27 + tap (the torch
+// weight row, zero-padded to a multiple of the MFMA K).  The weight operand is built once per wave
+// from the f32 weights (8 consecutive k per lane); the voxel operand is gathered from the staged
+// halo tile: 8 (bf16) / 4 (f32) single-element LDS reads per lane and k-step -- with K = 27 the
+// whole convolution of 16 voxels x 16 channels is ONE v_mfma_f32_16x16x32_bf16 for Cin = 1.
+// Tile = 4 x 8 x 16 output voxels (32 voxel tiles, 8 per wave); epilogue as conv_fwd_impl.h.
+// compile-time halo offset of k = ci*27 + tap (0 for the zero padding beyond 27*CIN)
+template <int CIN, int HD, int HH, int HW>
+__host__ __device__ constexpr int small_koff(int k) {
+  if (k >= 27 * CIN) return 0;
+  const int ci = k / 27, tap = k % 27;
+  return ((ci * HD + tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+}
+
+template <typename T, int S, int CIN>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) {
-  extern __shared__ float wsm[];  // [27*Cin][COUT] (tap-major so a tap's COUT weights are contiguous)
-  const int nk = 27 * p.Cin;
-  for (int i = threadIdx.x; i < nk * COUT; i += 256) {
-    const int co = i % COUT, k = i / COUT;         // k = ci*27 + tap
-    wsm[i] = p.w[(int64_t)co * nk + k];
-  }
-  __syncthreads();
-  const int64_t total = (int64_t)p.N * p.Do * p.Ho * p.Wo;
-  const T* in = (const T*)p.in;
-  T* out = (T*)p.out;
-  for (int64_t v = blockIdx.x * 256ll + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
-    int64_t t = v;
-    const int ox = t % p.Wo; t /= p.Wo;
-    const int oy = t % p.Ho; t /= p.Ho;
-    const int oz = t % p.Do;
-    const int n = t / p.Do;
-    float acc[COUT];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int KG = Elem<T>::KG;                      // k-values per lane per MFMA operand
+  constexpr int KSTEP = 4 * KG;                        // 32 (bf16) / 16 (f32)
+  constexpr int NK = (27 * CIN + KSTEP - 1) / KSTEP;   // k-steps
+  constexpr int TD = 4, TH = 8, TW = 16;
+  constexpr int HD = (TD - 1) * S + 3, HH = (TH - 1) * S + 3, HW = (TW - 1) * S + 3;
+  constexpr int NROWS = CIN * HD * HH;                 // halo rows of HW elements
+  constexpr int RPI = 256 / HW < HH ? 256 / HW : HH;   // rows staged per iteration (<= one row wrap)
+  constexpr int NIT = (NROWS + RPI - 1) / RPI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xs = reinterpret_cast<T*>(smem);                  // [CIN][HD][HH][HW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  int t = blockIdx.x;
+  const int txi = t % p.tx; t /= p.tx;
+  const int tyi = t % p.ty; t /= p.ty;
+  const int tzi = t % p.tz;
+  const int n = t / p.tz;
+  const int oz0 = tzi * TD, oy0 = tyi * TH, ox0 = txi * TW;
+  const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int co0 = blockIdx.y * 16;
+
+  // ---- halo tile -> LDS.  The index arithmetic of this layer used to cost more than everything
+  // else (212 quarter-rate integer multiplies per wave): a thread now owns one x position and walks
+  // the halo rows with running (ci, hz, hy) counters and a running 32-bit element offset from the
+  // wave-uniform tile origin; all loads are issued before the first LDS store.
+  const T* tile = (const T*)p.in + ((((int64_t)n * p.Di + iz0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi;
+  const int hx = tid % HW;
+  const bool xlive = tid < RPI * HW && (unsigned)(ix0 + hx) < (unsigned)p.Wi;
+  T stg[NIT];
+  {
+    static_assert(RPI <= HH, "at most one row wrap per iteration");
+    int row = tid / HW;                                // row = (ci * HD + hz) * HH + hy
+    int hy = row % HH, hz = (row / HH) % HD;
+    const int sy = p.Wi * p.ldi, sz = p.Hi * sy;        // element strides of one halo row / plane
+    int off = hz * sz + hy * sy + hx * p.ldi + row / (HH * HD);
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = p.bias ? p.bias[c] : 0.f;
-    for (int kd = 0; kd < 3; ++kd) {
-      const int z = oz * p.stride - 1 + kd;
-      if ((unsigned)z >= (unsigned)p.Di) continue;
-      for (int kh = 0; kh < 3; ++kh) {
-        const int y = oy * p.stride - 1 + kh;
-        if ((unsigned)y >= (unsigned)p.Hi) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int x = ox * p.stride - 1 + kw;
-          if ((unsigned)x >= (unsigned)p.Wi) continue;
-          const T* ip = in + ((((int64_t)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi;
-          const int tap = (kd * 3 + kh) * 3 + kw;
-          for (int ci = 0; ci < p.Cin; ++ci) {
-            const float a = Elem<T>::ld(ip + ci);
-            const float* wr = wsm + (ci * 27 + tap) * COUT;
-#pragma unroll
-            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(a, wr[c], acc[c]);
-          }
-        }
+    for (int k = 0; k < NIT; ++k) {
+      stg[k] = (T)0;
+      if (xlive && row < NROWS && (unsigned)(iz0 + hz) < (unsigned)p.Di &&
+          (unsigned)(iy0 + hy) < (unsigned)p.Hi)
+        stg[k] = tile[off];
+      row += RPI;
+      hy += RPI;
+      off += RPI * sy;
+      if (hy >= HH) {
+        hy -= HH;
+        off += sz - HH * sy;
+        if (++hz == HD) { hz = 0; off += 1 - HD * sz; }   // next input channel
       }
     }
-    if (p.alpha) {
-      const float al = *p.alpha;
+  }
+  if (tid < RPI * HW) {
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) acc[c] = acc[c] > 0.f ? acc[c] : al * acc[c];
+    for (int k = 0; k < NIT; ++k) {
+      const int row = tid / HW + RPI * k;
+      if (row < NROWS) xs[row * HW + hx] = stg[k];
     }
-    T* op = out + v * p.ldo;
-    const T* rp = p.res ? (const T*)p.res + v * p.ldr : nullptr;
+  }
+  // ---- weight operand: lane (co = r, g) holds k = KSTEP*s + KG*g + j; the halo offset of that k
+  // is a compile-time constant per lane group, plus the lane's voxel (x = r, plane z = wave)
+  frag_t wf[NK];
+  int lk[NK][KG];
+  const int lane_vox = (wave * S * HH) * HW + r * S;
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4) {
-      f32x4 o = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
-      if (rp) o += load4<T>(rp + c);
-      store4<T>(op + c, o);
+  for (int s = 0; s < NK; ++s) {
+    float wv[KG];
+#pragma unroll
+    for (int j = 0; j < KG; ++j) {
+      const int k = KSTEP * s + KG * g + j;
+      wv[j] = k < 27 * CIN ? p.w[(co0 + r) * 27 * CIN + k] : 0.f;
+      const int o0 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 0 + j);
+      const int o1 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 1 + j);
+      const int o2 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 2 + j);
+      const int o3 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 3 + j);
+      lk[s][j] = lane_vox + (g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3);
+    }
+    if constexpr (ES == 2) {
+      wf[s] = frag_t{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]),
+                     pack_bf16x2(wv[6], wv[7])};
+    } else {
+      wf[s] = frag_t{__float_as_uint(wv[0]), __float_as_uint(wv[1]), __float_as_uint(wv[2]),
+                     __float_as_uint(wv[3])};
+    }
+  }
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co0 + 4 * g);
+  const bool has_alpha = p.alpha != nullptr;
+  float alpha = has_alpha ? *p.alpha : 0.f;
+  touch_v(bias4);
+  touch_s(alpha);
+  __syncthreads();
+
+  // ---- wave w computes plane z = w of the tile; voxel tile i = row y = i (x = r)
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      frag_t a;
+      if constexpr (ES == 2) {
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = xs[lk[s][j] + i * S * HW];
+        a = frag_t{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                   (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(xs[lk[s][j] + i * S * HW]);
+      }
+      acc[i] = mma16<T>(wf[s], a, acc[i]);
+    }
+  }
+
+  // ---- epilogue: bias, BN statistics, PReLU, residual, 8/16-byte NDHWC stores; wave-uniform row
+  // pointers + one per-lane 32-bit offset
+  const int oz = oz0 + wave, ox = ox0 + r;
+  const bool zx_ok = oz < p.Do && ox < p.Wo;
+  T* orow = (T*)p.out + ((((int64_t)n * p.Do + oz) * p.Ho + oy0) * p.Wo) * p.ldo;
+  const T* rrow = p.res ? (const T*)p.res + ((((int64_t)n * p.Do + oz) * p.Ho + oy0) * p.Wo) * p.ldr
+                        : nullptr;
+  const unsigned lo_out = (unsigned)(ox * p.ldo + co0 + 4 * g), lo_res = (unsigned)(ox * p.ldr + co0 + 4 * g);
+  const int ostep = p.Wo * p.ldo, rstep = p.Wo * p.ldr;
+  f32x4 resv[8];
+  if (rrow) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      resv[i] = (zx_ok && oy0 + i < p.Ho) ? load4<T>(rrow + i * rstep + lo_res) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) touch_v(resv[i]);
+  }
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) touch_v(stg[k]);
+  f32x4 ssum = f32x4{0.f, 0.f, 0.f, 0.f}, ssq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x4 v = acc[i] + bias4;
+    if (zx_ok && oy0 + i < p.Ho) {
+      if (p.stats) { ssum += v; ssq += v * v; }
+      if (has_alpha) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+      }
+      if (rrow) v += resv[i];
+      store4<T>(orow + i * ostep + lo_out, v);
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][2][16]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = row16_sum(ssum[e]);
+      const float b0 = row16_sum(ssq[e]);
+      if (r == 0) {
+        red[(wave * 2 + 0) * 16 + 4 * g + e] = a0;
+        red[(wave * 2 + 1) * 16 + 4 * g + e] = b0;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid / 16, ch = tid % 16;
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * 16 + ch];
+      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + co0 + ch] = sacc;
     }
   }
 }
@@ -258,23 +391,52 @@ bool conv_small_ok(int cin, int cout, int ksize) {
   return ksize == 3 && cin >= 1 && cin <= 4 && (cout == 16 || cout == 32);
 }
 
-int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
-                   const float* bias, const float* alpha, const segmi_act* res, int stride,
-                   hipStream_t st) {
-  SmallConvParams p{};
-  p.in = in->data; p.out = out->data; p.w = w; p.bias = bias; p.alpha = alpha;
-  p.res = res ? res->data : nullptr; p.ldr = res ? res->ld : 0;
-  p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
-  p.Cin = in->c; p.ldi = in->ld; p.ldo = out->ld; p.stride = stride;
-  const int64_t total = act_voxels(out);
-  const int grid = (int)(cdiv64(total, 256) > 16384 ? 16384 : cdiv64(total, 256));
-  const size_t lds = (size_t)27 * in->c * out->c * sizeof(float);
-#define L(TT, CO) hipLaunchKernelGGL((conv_small_fwd_kernel<TT, CO>), grid, 256, lds, st, p)
-  if (dtype == SEGMI_F32) { if (out->c == 16) L(float, 16); else L(float, 32); }
-  else { if (out->c == 16) L(bf16_t, 16); else L(bf16_t, 32); }
-#undef L
+// partial-statistics rows of the small-Cin forward (= spatial workgroups)
+int conv_small_fwd_rows(const segmi_act* out) {
+  return out->n * cdiv(out->d, 4) * cdiv(out->h, 8) * cdiv(out->w, 16);
+}
+
+template <typename T, int S, int CIN>
+static int launch_small_fwd(SmallConvParams p, hipStream_t st) {
+  constexpr int HD = 3 * S + 3, HH = 7 * S + 3, HW = 15 * S + 3;
+  constexpr int stage = CIN * HD * HH * HW * (int)sizeof(T);
+  constexpr int lds = stage > 4 * 2 * 16 * 4 ? stage : 4 * 2 * 16 * 4;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_small_fwd_kernel<T, S, CIN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.Cout / 16));
+  hipLaunchKernelGGL((conv_small_fwd_kernel<T, S, CIN>), grid, 256, lds, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(small-cin)");
   return SEGMI_OK;
+}
+template <typename T, int S>
+static int launch_small_fwd_cin(const SmallConvParams& p, int cin, hipStream_t st) {
+  switch (cin) {
+    case 1: return launch_small_fwd<T, S, 1>(p, st);
+    case 2: return launch_small_fwd<T, S, 2>(p, st);
+    case 3: return launch_small_fwd<T, S, 3>(p, st);
+    default: return launch_small_fwd<T, S, 4>(p, st);
+  }
+}
+
+int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
+                   const float* bias, const float* alpha, const segmi_act* res, float* stats,
+                   int stride, hipStream_t st) {
+  SmallConvParams p{};
+  p.in = in->data; p.out = out->data; p.w = w; p.bias = bias; p.alpha = alpha;
+  p.res = res ? res->data : nullptr; p.ldr = res ? res->ld : 0; p.stats = stats;
+  p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
+  p.Cout = out->c; p.ldi = in->ld; p.ldo = out->ld;
+  p.tz = cdiv(out->d, 4); p.ty = cdiv(out->h, 8); p.tx = cdiv(out->w, 16);
+  SEGMI_CHECK_ARG((int64_t)p.N * p.tz * p.ty * p.tx < (1ll << 31), "conv3d: too many tiles");
+  if (dtype == SEGMI_F32)
+    return stride == 2 ? launch_small_fwd_cin<float, 2>(p, in->c, st)
+                       : launch_small_fwd_cin<float, 1>(p, in->c, st);
+  return stride == 2 ? launch_small_fwd_cin<bf16_t, 2>(p, in->c, st)
+                     : launch_small_fwd_cin<bf16_t, 1>(p, in->c, st);
 }
 
 int conv_small_wgrad_slabs(const segmi_act* dy) {

@@ -59,7 +59,11 @@ CONV_CASES = [
     (128, 48, 3, 1, (5, 6, 7), 2),       # k-split kernel, odd tile count, narrow + ragged tiles
     (64, 64, 3, 1, (9, 10, 40), 2),      # k-split kernel, wide tiles, two output tiles per workgroup
     (256, 32, 3, 1, (8, 8, 8), 1),       # k-split kernel, 8 bf16 / 16 f32 chunks
-    (1, 16, 3, 2, (12, 12, 12), 2),   # direct kernel (first layer)
+    (1, 16, 3, 2, (12, 12, 12), 2),   # small-Cin MFMA kernel (first layer)
+    (1, 16, 3, 2, (20, 34, 70), 1),   # small-Cin, several ragged tiles
+    (2, 32, 3, 1, (5, 9, 19), 2),     # small-Cin, stride 1, two output tiles, 2 k-steps
+    (4, 16, 3, 2, (9, 9, 9), 1),      # small-Cin, 4 input channels (108 k-values)
+    (3, 16, 3, 1, (4, 8, 16), 1),
     (16, 3, 3, 1, (6, 7, 9), 1),      # direct kernel (K=3 head)
     (4, 8, 3, 2, (9, 9, 9), 1),       # direct kernel, odd extents
 ]
