@@ -1,0 +1,361 @@
+// conv_ring2_impl.h -- second formulation of the z-marching ring (conv_ring_impl.h) for bf16
+// single-chunk k3 s1 layers: the network's wide 16 -> 16 and 32 -> 32 convolutions.
+//
+// conv_ring_mfma_kernel gives a wave one output plane x 8 rows and reads one 1-KiB LDS fragment per
+// MFMA and output tile: for Cout = 16 that is 288 B/clk/CU of LDS reads against the 128 B/clk the
+// LDS delivers (<= 44 % MFMA utilisation, 27 % measured), and its 32-channel variants spill.
+// Here a wave owns 2 y-rows x ALL 4 output planes of the step, so a voxel fragment of input plane
+// p feeds the taps kd = 0,1,2 of output planes p+1, p, p-1 from registers (60 fragment reads per
+// 120 MFMAs for 16 channels instead of 126 per 112), and every weight fragment lives in registers
+// for the whole column: 15 fragments (60 VGPRs) for 16 -> 16, 54 fragments (216 VGPRs, one
+// workgroup per CU -- the 144 KB ring allows no more anyway) for 32 -> 32.
+//
+// k-steps are organised per kd so that a voxel fragment is independent of kd:
+//   CK = 16 (two taps per k-step): 5 k-steps per kd pairing (kh,kw) taps (0,1)(2,3)(4,5)(6,7)(8,-);
+//            the fragments are gathered once from the standard pack (tap T sits in k-step T/2 at
+//            lane group (T&1)*2 + (g&1)), the 10th slot is a zero weight;
+//   CK = 32 (one tap per k-step): 9 k-steps per kd, the standard pack order.
+// Index arithmetic: every per-lane quantity is a 32-bit offset inside a plane computed once, every
+// per-step quantity a wave-uniform plane pointer -- no integer multiplies in the step loop (the
+// first version spent more issue cycles on 64-bit voxel addresses than on its MFMAs).
+#pragma once
+#include "conv_ring_impl.h"
+
+namespace segmi {
+
+template <typename T, int CK, int NT>
+__global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvParams p) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using G = RingGeom<T, CK>;
+  constexpr int J = G::SPT == 2 ? 5 : 9;     // k-steps per kd
+  constexpr int NIT = 6 * J;                 // (input plane, k-step) iterations per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+
+  int t = blockIdx.x;
+  const int seg = t % p.tz; t /= p.tz;
+  const int txi = t % p.tx; t /= p.tx;
+  const int tyi = t % p.ty;
+  const int n = t / p.ty;
+  const int oy0 = tyi * G::TH, ox0 = txi * G::TW;
+  const int nt0 = blockIdx.y * NT;
+  const int total_steps = (p.Do + G::TD - 1) / G::TD;
+  const int seg_steps = (total_steps + p.tz - 1) / p.tz;
+  const int z0 = seg * seg_steps * G::TD;
+  const int nsteps_z = total_steps - seg * seg_steps < seg_steps ? total_steps - seg * seg_steps
+                                                                : seg_steps;
+
+  // ---- weights -> registers
+  frag_t wreg[3][J][NT];
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        wreg[kd][j][jt] = frag_t{0u, 0u, 0u, 0u};
+        if constexpr (G::SPT == 2) {
+          const int t9 = 2 * j + (g >> 1);
+          if (t9 <= 8) {
+            const int tap = kd * 9 + t9;
+            const int sp = tap >> 1, gp = (tap & 1) * 2 + (g & 1);
+            wreg[kd][j][jt] = *reinterpret_cast<const frag_t*>(
+                (const char*)p.wfrag + (((int64_t)sp * p.ntiles_total + nt0 + jt) * 64 + gp * 16 + r) * 16);
+          }
+        } else {
+          wreg[kd][j][jt] = *reinterpret_cast<const frag_t*>(
+              (const char*)p.wfrag + (((int64_t)(kd * 9 + j) * p.ntiles_total + nt0 + jt) * 64 + lane) * 16);
+        }
+      }
+  // per-lane part of the voxel-fragment address of k-step j (inside a plane, row 0 of the wave)
+  int laneoff[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    if constexpr (G::SPT == 2) {
+      int t9 = 2 * j + (g >> 1);
+      if (t9 > 8) t9 = 8;
+      laneoff[j] = ((t9 / 3) * G::HW + t9 % 3 + r) * G::ROWB + (g & 1) * 16;
+    } else {
+      laneoff[j] = ((j / 3) * G::HW + j % 3 + r) * G::ROWB + g * 16;
+    }
+  }
+  const int wrow = wave * 2 * G::HW * G::ROWB;   // the wave's first y-row
+
+  // ---- staging descriptors: 32-bit offsets inside a plane, computed once
+  constexpr int NLP = (G::PLANE_CHUNKS + 255) / 256;   // 16-byte chunks per thread per plane
+  const char* inb = (const char*)p.in;
+  const int64_t plane_stride = (int64_t)p.Hi * p.Wi * p.ldi * (int64_t)sizeof(T);
+  const char* img = inb + (int64_t)n * p.Di * plane_stride;
+  int g_off[NLP], l_off[NLP];
+#pragma unroll
+  for (int q = 0; q < NLP; ++q) {
+    const int i = tid + 256 * q;
+    const int row = i / G::CPR, ch = i % G::CPR;
+    const int hy = row / G::HW, hx = row % G::HW;
+    const int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
+    const bool ok = i < G::PLANE_CHUNKS && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    l_off[q] = i < G::PLANE_CHUNKS ? row * G::ROWB + ch * 16 : -1;
+    g_off[q] = ok ? (y * p.Wi + x) * p.ldi * (int)sizeof(T) + ch * 16 : -1;
+  }
+  // prologue: planes z0-1 .. z0+4 -> ring slots 0 .. 5
+#pragma unroll
+  for (int pl = 0; pl < 6; ++pl) {
+    const int z = z0 + pl - 1;
+    const char* pp = img + (int64_t)z * plane_stride;
+#pragma unroll
+    for (int q = 0; q < NLP; ++q) {
+      frag_t val = frag_t{0u, 0u, 0u, 0u};
+      if ((unsigned)z < (unsigned)p.Di && g_off[q] >= 0)
+        val = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+      if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + pl * G::PLANE_B + l_off[q]) = val;
+    }
+  }
+  __syncthreads();
+
+  f32x4 bias4[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    bias4[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4[jt] = *reinterpret_cast<const f32x4*>(p.bias + (nt0 + jt) * 16 + 4 * g);
+    touch_v(bias4[jt]);
+  }
+  const bool has_alpha = p.alpha != nullptr;
+  float alpha = has_alpha ? *p.alpha : 0.f;
+  touch_s(alpha);
+  f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) { ssum[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  T* outp = (T*)p.out;
+  const T* resp = (const T*)p.res;
+  // identity residual (out = conv(x) + x): the rows are the centre plane of the ring
+  const bool res_in = resp && p.res == p.in && p.ldr == p.ldi && p.Cin == p.Cout;
+  const int co = nt0 * 16 + 4 * g;
+  // per-lane element offsets of the wave's two output rows inside an output plane
+  unsigned o_off[2], r_off[2];
+  bool row_ok[2];
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro) {
+    const int oy = oy0 + 2 * wave + ro, ox = ox0 + r;
+    row_ok[ro] = oy < p.Ho && ox < p.Wo;
+    o_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldo + co);
+    r_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldr + co);
+  }
+  const int64_t oplane = (int64_t)p.Ho * p.Wo * p.ldo, rplane = (int64_t)p.Ho * p.Wo * p.ldr;
+
+  for (int step = 0; step < nsteps_z; ++step) {
+    const int zb = step * G::TD;
+    const bool more = step + 1 < nsteps_z;
+    // ---- issue the global loads of the NEXT step's 4 new planes (z = z0 + zb + 5 .. + 8)
+    frag_t stg[G::TD][NLP];
+#pragma unroll
+    for (int pl = 0; pl < G::TD; ++pl) {
+      const int z = z0 + zb + 5 + pl;
+      const char* pp = img + (int64_t)z * plane_stride;
+      const bool zok = more && z < p.Di;
+#pragma unroll
+      for (int q = 0; q < NLP; ++q) {
+        stg[pl][q] = frag_t{0u, 0u, 0u, 0u};
+        if (zok && g_off[q] >= 0) stg[pl][q] = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+      }
+    }
+    // residual rows of this step's outputs (4 planes x 2 rows), unless they are the input itself
+    // (32-channel variant: 216 weight VGPRs leave no room for 32 more; it fetches them per plane
+    // in the epilogue instead)
+    constexpr bool PRE_RES = CK == 16;
+    typename Raw4<T>::type resv[PRE_RES ? 4 : 1][2][NT];
+    if (PRE_RES && resp && !res_in) {
+#pragma unroll
+      for (int zi = 0; zi < 4; ++zi) {
+        const int oz = z0 + zb + zi;
+        const T* rp = resp + ((int64_t)n * p.Do + oz) * rplane;
+#pragma unroll
+        for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+            resv[zi][ro][jt] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(rp + r_off[ro] + jt * 16)
+                                                         : typename Raw4<T>::type{};
+      }
+    }
+    // ---- compute: input plane c (z = zb - 1 + c) lives in ring slot (zb + c) % R
+    f32x4 acc[4][2][NT];
+#pragma unroll
+    for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+      for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) acc[zi][ro][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int pofs[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c) % G::R) * G::PLANE_B + wrow;
+    // software pipeline over the (plane, k-step) iterations, fragments two iterations ahead
+    frag_t a[3][2];
+    auto issue = [&](int it, frag_t (&dst)[2]) {
+      const int c = it / J, j = it % J;
+      dst[0] = *reinterpret_cast<const frag_t*>(smem + pofs[c] + laneoff[j]);
+      dst[1] = *reinterpret_cast<const frag_t*>(smem + pofs[c] + laneoff[j] + G::HW * G::ROWB);
+    };
+    issue(0, a[0]);
+    issue(1, a[1]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it + 2 < NIT) issue(it + 2, a[(it + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int c = it / J, j = it % J;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int zi = c - kd;
+        if (zi >= 0 && zi < 4) {
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            acc[zi][0][jt] = mma16<T>(wreg[kd][j][jt], a[it % 3][0], acc[zi][0][jt]);
+            acc[zi][1][jt] = mma16<T>(wreg[kd][j][jt], a[it % 3][1], acc[zi][1][jt]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- write the prefetched planes into the free ring slots (zb+6 .. zb+9 mod R)
+    if (more) {
+#pragma unroll
+      for (int pl = 0; pl < G::TD; ++pl) {
+        const int slot = (zb + 6 + pl) % G::R;
+#pragma unroll
+        for (int q = 0; q < NLP; ++q)
+          if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = stg[pl][q];
+      }
+    }
+    // every staging register is dead from here on; say so on ALL control-flow paths (touch_v)
+#pragma unroll
+    for (int pl = 0; pl < G::TD; ++pl)
+#pragma unroll
+      for (int q = 0; q < NLP; ++q) touch_v(stg[pl][q]);
+    auto lds_res = [&](int zi, typename Raw4<T>::type (&dst)[2][NT]) {
+      // centre plane of output plane zi is input plane c = zi + 1
+#pragma unroll
+      for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          dst[ro][jt] = *reinterpret_cast<const typename Raw4<T>::type*>(
+              smem + pofs[zi + 1] + ((ro + 1) * G::HW + r + 1) * G::ROWB +
+              (co + jt * 16) * (int)sizeof(T));
+    };
+    if constexpr (PRE_RES) {
+      if (res_in) {
+#pragma unroll
+        for (int zi = 0; zi < 4; ++zi) lds_res(zi, resv[zi]);
+      }
+      if (resp) {
+#pragma unroll
+        for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+          for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) touch_v(resv[zi][ro][jt]);
+      }
+    }
+    // ---- epilogue of this step
+#pragma unroll
+    for (int zi = 0; zi < 4; ++zi) {
+      const int oz = z0 + zb + zi;
+      T* op = outp + ((int64_t)n * p.Do + oz) * oplane;   // wave-uniform plane pointer
+      const int rz = PRE_RES ? zi : 0;
+      if constexpr (!PRE_RES) {
+        if (res_in) {
+          lds_res(zi, resv[0]);
+        } else if (resp) {
+          const T* rp = resp + ((int64_t)n * p.Do + oz) * rplane;
+#pragma unroll
+          for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+              resv[0][ro][jt] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(rp + r_off[ro] + jt * 16)
+                                                          : typename Raw4<T>::type{};
+        }
+        if (resp) {
+#pragma unroll
+          for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) touch_v(resv[0][ro][jt]);
+        }
+      }
+#pragma unroll
+      for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          f32x4 v = acc[zi][ro][jt] + bias4[jt];
+          if (oz < p.Do && row_ok[ro]) {
+            if (p.stats) { ssum[jt] += v; ssq[jt] += v * v; }
+            if (has_alpha) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+            }
+            if (resp) v += Raw4<T>::cvt(resv[rz][ro][jt]);
+            store4<T>(op + o_off[ro] + jt * 16, v);
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]  (ring no longer needed)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = row16_sum(ssum[jt][e]);
+        const float b0 = row16_sum(ssq[jt][e]);
+        if (r == 0) {
+          red[(wave * 2 + 0) * NT * 16 + jt * 16 + 4 * g + e] = a0;
+          red[(wave * 2 + 1) * NT * 16 + jt * 16 + 4 * g + e] = b0;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * NT * 16) {
+      const int which = tid / (NT * 16), ch = tid % (NT * 16);
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
+      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
+    }
+  }
+}
+
+template <typename T, int CK, int NT>
+static int launch_conv_ring2_cfg(ConvParams p, hipStream_t st) {
+  using G = RingGeom<T, CK>;
+  constexpr int dt = SEGMI_BF16;
+  p.tz = conv_ring_zsplit(dt, p.Cin, 3, 1, p.N, p.Do, p.Ho, p.Wo);
+  p.ty = cdiv(p.Ho, G::TH);
+  p.tx = cdiv(p.Wo, G::TW);
+  // 32-bit byte offsets inside one input / output plane
+  SEGMI_CHECK_ARG((int64_t)p.Hi * p.Wi * p.ldi * 2 < (1ll << 31) && (int64_t)p.Ho * p.Wo * p.ldo < (1ll << 31) &&
+                      (int64_t)p.Ho * p.Wo * (p.ldr > 0 ? p.ldr : 1) < (1ll << 31),
+                  "conv3d: plane too large for the ring kernel's 32-bit offsets");
+  dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
+  auto kern = conv_ring2_kernel<T, CK, NT>;
+  static bool attr_done = false;
+  if (!attr_done && G::LDS_BYTES > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES, st, p);
+  SEGMI_LAUNCH_CHECK("conv3d_fwd(ring2)");
+  return SEGMI_OK;
+}
+
+// bf16 ring layers: 16 -> 16*m and 32 -> 32*m
+static int launch_conv_ring2(const ConvParams& p, hipStream_t st) {
+  const int ck = pick_ck(SEGMI_BF16, p.Cin);
+  const int nt = p.Cout / 16;
+  if (ck == 32) {
+    if (nt % 2 == 0) return launch_conv_ring2_cfg<bf16_t, 32, 2>(p, st);
+    return launch_conv_ring2_cfg<bf16_t, 32, 1>(p, st);
+  }
+  return launch_conv_ring2_cfg<bf16_t, 16, 1>(p, st);
+}
+
+}  // namespace segmi

@@ -303,260 +303,6 @@ __global__ __launch_bounds__(256, 2) void conv_ring_mfma_kernel(ConvParams p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Second formulation of the same ring for the 16 -> 16 channel bf16 layers (the network's
-// full-resolution convolutions).  conv_ring_mfma_kernel reads one 1-KiB LDS fragment per MFMA
-// (Cout = 16 gives no reuse across output tiles): 9 KiB of LDS reads per 8 MFMAs per wave =
-// 288 B/clk/CU against the 128 B/clk the LDS delivers, i.e. the kernel is LDS-bandwidth bound at
-// <= 44 % MFMA utilisation (27 % measured).  Here a wave owns 2 y-rows x ALL 4 output planes of the
-// step, so a voxel fragment of input plane p feeds the three taps kd = 0,1,2 of output planes
-// p+1, p, p-1 from registers: 60 fragment reads per 120 MFMAs instead of 126 per 112.  To make the
-// fragment independent of kd, a k-step pairs two (kh,kw) taps of the SAME kd (5 k-steps per kd,
-// the 10th slot is a zero weight); the 15 weight fragments are gathered once from the standard
-// pack into 60 VGPRs and never re-read.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_ring2_kernel(ConvParams p) {
-  static_assert(sizeof(T) == 2, "bf16 only");
-  constexpr int CK = 16, NT = 1;
-  using G = RingGeom<T, CK>;
-  static_assert(G::SPT == 2 && G::ROWB == 32, "16 bf16 channels per row");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, r = lane & 15;
-
-  int t = blockIdx.x;
-  const int seg = t % p.tz; t /= p.tz;
-  const int txi = t % p.tx; t /= p.tx;
-  const int tyi = t % p.ty;
-  const int n = t / p.ty;
-  const int oy0 = tyi * G::TH, ox0 = txi * G::TW;
-  const int total_steps = (p.Do + G::TD - 1) / G::TD;
-  const int seg_steps = (total_steps + p.tz - 1) / p.tz;
-  const int z0 = seg * seg_steps * G::TD;
-  const int nsteps_z = total_steps - seg * seg_steps < seg_steps ? total_steps - seg * seg_steps
-                                                                : seg_steps;
-
-  // ---- weights: (kd, j) fragment = taps kd*9 + 2j + (g>>1), channel half g&1, gathered from the
-  // standard pack where tap T sits in k-step T/2 at lane group (T&1)*2 + (g&1)
-  frag_t wreg[3][5];
-#pragma unroll
-  for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int t9 = 2 * j + (g >> 1);
-      wreg[kd][j] = frag_t{0u, 0u, 0u, 0u};
-      if (t9 <= 8) {
-        const int tap = kd * 9 + t9;
-        const int sp = tap >> 1, gp = (tap & 1) * 2 + (g & 1);
-        wreg[kd][j] = *reinterpret_cast<const frag_t*>(
-            (const char*)p.wfrag + (((int64_t)sp * p.ntiles_total + blockIdx.y) * 64 + gp * 16 + r) * 16);
-      }
-    }
-  // per-lane part of the voxel-fragment address of k-step j (inside a plane, row 0 of the wave)
-  int laneoff[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    int t9 = 2 * j + (g >> 1);
-    if (t9 > 8) t9 = 8;
-    laneoff[j] = ((t9 / 3) * G::HW + t9 % 3 + r) * G::ROWB + (g & 1) * 16;
-  }
-  const int wrow = wave * 2 * G::HW * G::ROWB;   // the wave's first y-row
-
-  // ---- staging descriptors.  Index arithmetic is the bottleneck of this kernel family (the first
-  // version spent 83 quarter-rate integer multiplies per wave and step on 64-bit voxel addresses --
-  // more issue cycles than its 112 MFMAs), so everything per-lane is computed ONCE as a 32-bit
-  // offset inside a plane and every per-step quantity is a wave-uniform plane pointer (SALU):
-  // loads and stores use the "SGPR base + VGPR offset" form with no VALU address math at all.
-  constexpr int NLP = (G::PLANE_CHUNKS + 255) / 256;   // 16-byte chunks per thread per plane
-  const char* inb = (const char*)p.in;
-  const int64_t plane_stride = (int64_t)p.Hi * p.Wi * p.ldi * (int64_t)sizeof(T);
-  const char* img = inb + (int64_t)n * p.Di * plane_stride;
-  int g_off[NLP], l_off[NLP];
-#pragma unroll
-  for (int q = 0; q < NLP; ++q) {
-    const int i = tid + 256 * q;
-    const int row = i / G::CPR, ch = i % G::CPR;
-    const int hy = row / G::HW, hx = row % G::HW;
-    const int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
-    const bool ok = i < G::PLANE_CHUNKS && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-    l_off[q] = i < G::PLANE_CHUNKS ? row * G::ROWB + ch * 16 : -1;
-    g_off[q] = ok ? (y * p.Wi + x) * p.ldi * (int)sizeof(T) + ch * 16 : -1;
-  }
-  // prologue: planes z0-1 .. z0+4 -> ring slots 0 .. 5
-#pragma unroll
-  for (int pl = 0; pl < 6; ++pl) {
-    const int z = z0 + pl - 1;
-    const char* pp = img + (int64_t)z * plane_stride;
-#pragma unroll
-    for (int q = 0; q < NLP; ++q) {
-      frag_t val = frag_t{0u, 0u, 0u, 0u};
-      if ((unsigned)z < (unsigned)p.Di && g_off[q] >= 0)
-        val = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
-      if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + pl * G::PLANE_B + l_off[q]) = val;
-    }
-  }
-  __syncthreads();
-
-  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + blockIdx.y * 16 + 4 * g);
-  const bool has_alpha = p.alpha != nullptr;
-  float alpha = has_alpha ? *p.alpha : 0.f;
-  touch_v(bias4);
-  touch_s(alpha);
-  f32x4 ssum = f32x4{0.f, 0.f, 0.f, 0.f}, ssq = f32x4{0.f, 0.f, 0.f, 0.f};
-  T* outp = (T*)p.out;
-  const T* resp = (const T*)p.res;
-  const bool res_in = resp && p.res == p.in && p.ldr == p.ldi && p.Cin == p.Cout;
-  const int co = blockIdx.y * 16 + 4 * g;
-  // per-lane element offsets of the wave's two output rows inside an output plane
-  unsigned o_off[2], r_off[2];
-  bool row_ok[2];
-#pragma unroll
-  for (int ro = 0; ro < 2; ++ro) {
-    const int oy = oy0 + 2 * wave + ro, ox = ox0 + r;
-    row_ok[ro] = oy < p.Ho && ox < p.Wo;
-    o_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldo + co);
-    r_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldr + co);
-  }
-  const int64_t oplane = (int64_t)p.Ho * p.Wo * p.ldo, rplane = (int64_t)p.Ho * p.Wo * p.ldr;
-
-  for (int step = 0; step < nsteps_z; ++step) {
-    const int zb = step * G::TD;
-    const bool more = step + 1 < nsteps_z;
-    // ---- issue the global loads of the NEXT step's 4 new planes (z = z0 + zb + 5 .. + 8)
-    frag_t stg[G::TD][NLP];
-#pragma unroll
-    for (int pl = 0; pl < G::TD; ++pl) {
-      const int z = z0 + zb + 5 + pl;
-      const char* pp = img + (int64_t)z * plane_stride;
-      const bool zok = more && z < p.Di;
-#pragma unroll
-      for (int q = 0; q < NLP; ++q) {
-        stg[pl][q] = frag_t{0u, 0u, 0u, 0u};
-        if (zok && g_off[q] >= 0) stg[pl][q] = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
-      }
-    }
-    // residual rows of this step's outputs (4 planes x 2 rows), unless they are the input itself
-    typename Raw4<T>::type resv[4][2];
-    if (resp && !res_in) {
-#pragma unroll
-      for (int zi = 0; zi < 4; ++zi) {
-        const int oz = z0 + zb + zi;
-        const T* rp = resp + ((int64_t)n * p.Do + oz) * rplane;
-#pragma unroll
-        for (int ro = 0; ro < 2; ++ro)
-          resv[zi][ro] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(rp + r_off[ro])
-                                                   : typename Raw4<T>::type{};
-      }
-    }
-    // ---- compute: input plane c (z = zb - 1 + c) lives in ring slot (zb + c) % R
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int zi = 0; zi < 4; ++zi)
-#pragma unroll
-      for (int ro = 0; ro < 2; ++ro) acc[zi][ro] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int pofs[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c) % G::R) * G::PLANE_B + wrow;
-    // software pipeline over the 30 (plane, k-step) iterations, fragments two iterations ahead
-    frag_t a[3][2];
-    auto issue = [&](int it, frag_t (&dst)[2]) {
-      const int c = it / 5, j = it % 5;
-      dst[0] = *reinterpret_cast<const frag_t*>(smem + pofs[c] + laneoff[j]);
-      dst[1] = *reinterpret_cast<const frag_t*>(smem + pofs[c] + laneoff[j] + G::HW * G::ROWB);
-    };
-    issue(0, a[0]);
-    issue(1, a[1]);
-#pragma unroll
-    for (int it = 0; it < 30; ++it) {
-      if (it + 2 < 30) issue(it + 2, a[(it + 2) % 3]);
-      __builtin_amdgcn_sched_barrier(0);
-      const int c = it / 5, j = it % 5;
-#pragma unroll
-      for (int kd = 0; kd < 3; ++kd) {
-        const int zi = c - kd;
-        if (zi >= 0 && zi < 4) {
-          acc[zi][0] = mma16<T>(wreg[kd][j], a[it % 3][0], acc[zi][0]);
-          acc[zi][1] = mma16<T>(wreg[kd][j], a[it % 3][1], acc[zi][1]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- write the prefetched planes into the free ring slots (zb+6 .. zb+9 mod R)
-    if (more) {
-#pragma unroll
-      for (int pl = 0; pl < G::TD; ++pl) {
-        const int slot = (zb + 6 + pl) % G::R;
-#pragma unroll
-        for (int q = 0; q < NLP; ++q)
-          if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = stg[pl][q];
-      }
-    }
-    // every staging register is dead from here on; say so on ALL control-flow paths, otherwise
-    // each conditionally executed epilogue block below re-waits (vmcnt(0)) before reusing them
-#pragma unroll
-    for (int pl = 0; pl < G::TD; ++pl)
-#pragma unroll
-      for (int q = 0; q < NLP; ++q) touch_v(stg[pl][q]);
-    if (res_in) {   // centre plane of output plane zi is input plane c = zi + 1
-#pragma unroll
-      for (int zi = 0; zi < 4; ++zi)
-#pragma unroll
-        for (int ro = 0; ro < 2; ++ro)
-          resv[zi][ro] = *reinterpret_cast<const typename Raw4<T>::type*>(
-              smem + pofs[zi + 1] + ((ro + 1) * G::HW + r + 1) * G::ROWB + co * (int)sizeof(T));
-    }
-    if (resp) {
-#pragma unroll
-      for (int zi = 0; zi < 4; ++zi)
-#pragma unroll
-        for (int ro = 0; ro < 2; ++ro) touch_v(resv[zi][ro]);
-    }
-    // ---- epilogue of this step
-#pragma unroll
-    for (int zi = 0; zi < 4; ++zi) {
-      const int oz = z0 + zb + zi;
-      T* op = outp + ((int64_t)n * p.Do + oz) * oplane;   // wave-uniform plane pointer
-#pragma unroll
-      for (int ro = 0; ro < 2; ++ro) {
-        f32x4 v = acc[zi][ro] + bias4;
-        if (oz < p.Do && row_ok[ro]) {
-          if (p.stats) { ssum += v; ssq += v * v; }
-          if (has_alpha) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
-          }
-          if (resp) v += Raw4<T>::cvt(resv[zi][ro]);
-          store4<T>(op + o_off[ro], v);
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [wave][2][16]
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a0 = row16_sum(ssum[e]);
-      const float b0 = row16_sum(ssq[e]);
-      if (r == 0) {
-        red[(wave * 2 + 0) * 16 + 4 * g + e] = a0;
-        red[(wave * 2 + 1) * 16 + 4 * g + e] = b0;
-      }
-    }
-    __syncthreads();
-    if (tid < 32) {
-      const int which = tid / 16, ch = tid % 16;
-      float sacc = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * 16 + ch];
-      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + blockIdx.y * 16 + ch] = sacc;
-    }
-  }
-}
-
 // Plan: columns = N * ceil(H/8) * ceil(W/16); each column is cut into `zsplit` z-segments so that
 // >= ~512 workgroups exist, as long as every segment keeps >= 4 steps (else the 2-plane prologue
 // overhead and the lost pipelining make the tile-at-a-time kernel the better choice).
@@ -614,20 +360,6 @@ static int launch_conv_ring_t(const ConvParams& p, hipStream_t st) {
     }
   }
   if (nt % 2 == 0) return launch_conv_ring_cfg<T, 16, 2>(p, st);
-  if constexpr (sizeof(T) == 2) {
-    static const bool v1 = getenv("SEGMI_RING_V1") != nullptr;
-    if (!v1) {
-      using G = RingGeom<T, 16>;
-      ConvParams q = p;
-      q.tz = conv_ring_zsplit(dt, p.Cin, 3, 1, p.N, p.Do, p.Ho, p.Wo);
-      q.ty = cdiv(p.Ho, G::TH);
-      q.tx = cdiv(p.Wo, G::TW);
-      dim3 grid((unsigned)(q.N * q.ty * q.tx * q.tz), (unsigned)nt);
-      hipLaunchKernelGGL(conv_ring2_kernel<T>, grid, 256, G::LDS_BYTES, st, q);
-      SEGMI_LAUNCH_CHECK("conv3d_fwd(ring2)");
-      return SEGMI_OK;
-    }
-  }
   return launch_conv_ring_cfg<T, 16, 1>(p, st);
 }
 
