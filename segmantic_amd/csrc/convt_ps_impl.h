@@ -2,7 +2,7 @@
 // (top of the decoder and the dgrad of the first stride-2 convs), where the op is HBM-bound and
 // the tile kernel of convt_fwd_impl.h is latency/VALU-bound (1.8-2.0 TB/s measured).
 //
-//  * every weight fragment of the layer (<= 54 KB: 16 output channels, one or two channel chunks) is staged into LDS once
+//  * every weight fragment of the layer (<= 54 KB: 16 output channels and one or two channel chunks, or 32 -> 32 in bf16) is staged into LDS once
 //    per workgroup and reused over `tiles_per_wg` consecutive input tiles (2 x 2 x 16 voxels);
 //  * the next tile's halo (3 x 3 x 17 voxels, all channels) is fetched into registers while the
 //    current one is multiplied and stored;
@@ -34,7 +34,7 @@ static inline bool convt_ps_ok(int dtype, int cin, int cout, int wi) {
   const int ck = dtype == SEGMI_F32 ? 16 : 32;
   if (cin % ck || cout % 16 || wi < 16) return false;
   const int nch = cin / ck, nt = cout / 16;
-  return nt == 1 && nch <= 2;
+  return (nt == 1 && nch <= 2) || (nt == 2 && nch == 1 && dtype == SEGMI_BF16);
 }
 
 // partial-statistics rows the MFMA transposed-conv path writes (one per workgroup)
@@ -105,7 +105,7 @@ struct CtPsGeom {
 };
 
 template <typename T, int NT, int NCH>
-__global__ __launch_bounds__(256, 2) void convt_ps_kernel(ConvTParams p, int ntiles, int per_wg) {
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTParams p, int ntiles, int per_wg) {
   using G = CtPsGeom<T, NT, NCH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wl = smem;
@@ -323,7 +323,11 @@ template <typename T>
 static int launch_convt_ps_t(const ConvTParams& p, hipStream_t st) {
   constexpr int CK = sizeof(T) == 2 ? 32 : 16;
   const int nch = p.Cin / CK, nt = p.Cout / 16;
-  SEGMI_CHECK_ARG(nt == 1 && (nch == 1 || nch == 2), "convT3d: persistent kernel misuse");
+  SEGMI_CHECK_ARG((nt == 1 && (nch == 1 || nch == 2)) || (nt == 2 && nch == 1),
+                  "convT3d: persistent kernel misuse");
+  if constexpr (sizeof(T) == 2) {
+    if (nt == 2) return launch_convt_ps_cfg<T, 2, 1>(p, st);
+  }
   if (nch == 1) return launch_convt_ps_cfg<T, 1, 1>(p, st);
   return launch_convt_ps_cfg<T, 1, 2>(p, st);
 }

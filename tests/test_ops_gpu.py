@@ -220,6 +220,7 @@ CONVT_CASES = [
     (64, 16, (5, 3, 33), 1, 0),   # persistent kernel, two bf16 chunks, ragged x tiles
     (32, 16, (3, 4, 16), 2, 1),   # persistent kernel, odd output extent
     (32, 16, (24, 40, 48), 3, 0), # persistent kernel, several tiles per workgroup + ragged tail
+    (32, 32, (5, 6, 36), 2, 0),   # persistent kernel, two output tiles (K = 32 decoder top)
 ]
 
 
@@ -272,7 +273,8 @@ def test_convT3d_fwd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(32, 16, (4, 6, 20), 2), (64, 16, (3, 3, 16), 1), (128, 32, (4, 4, 8), 1)])
+@pytest.mark.parametrize("case", [(32, 16, (4, 6, 20), 2), (64, 16, (3, 3, 16), 1), (128, 32, (4, 4, 8), 1),
+                                  (32, 32, (3, 4, 18), 1)])
 def test_convT3d_epilogue_prelu_residual(case, dtype):
     """PReLU + residual epilogue (the form the dgrad of a stride-2 conv uses) on both kernels."""
     cin, cout, sp, n = case
