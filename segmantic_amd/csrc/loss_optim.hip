@@ -132,11 +132,11 @@ struct DiceFin {
     }
     red[tid] = local;
     __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int i = 0; i < 256; ++i) t += red[i];
-      *loss = (float)(t / nk);
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
     }
+    if (tid == 0) *loss = (float)(red[0] / nk);
   }
 };
 

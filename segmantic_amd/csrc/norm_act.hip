@@ -285,11 +285,11 @@ struct BnBwdFin {
       for (int cc = threadIdx.x; cc < c; cc += 256) t += sums[2 * c + cc];
       red[threadIdx.x] = t;
       __syncthreads();
-      if (threadIdx.x == 0) {
-        double a = 0.0;
-        for (int i = 0; i < 256; ++i) a += red[i];
-        *dalpha = (float)a;
+      for (int o = 128; o > 0; o >>= 1) {     // fixed-shape tree: deterministic, 8 steps instead of 256
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
       }
+      if (threadIdx.x == 0) *dalpha = (float)red[0];
     }
   }
 };

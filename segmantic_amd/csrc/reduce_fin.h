@@ -26,7 +26,12 @@ constexpr int kFinScratchRows = kFinBlocks + 1;   // f64 rows of `width` behind 
 static __device__ unsigned int g_fin_tickets[kFinTickets];
 static std::atomic<unsigned> g_fin_next{0};
 
-static inline int fin_blocks(int rows) {
+// Small tables (<= 64 K floats) are folded by ONE workgroup: the multi-block path costs four
+// dependent device-scope round trips (rows -> scratch -> fence + ticket -> scratch -> result, ~16 us
+// measured) where a single block needs one; its column sums use 16 independent accumulators per
+// thread so the loads of a thread are in flight together.
+static inline int fin_blocks(int rows, int width) {
+  if ((int64_t)rows * width <= 65536) return 1;
   int b = rows / 8;
   return b < 1 ? 1 : (b > kFinBlocks ? kFinBlocks : b);
 }
@@ -50,6 +55,15 @@ __global__ __launch_bounds__(256) void collapse_fin_kernel(const float* __restri
     if (lane < rl && e < width) {
       const int step = nblk * rl;
       int r = blockIdx.x * rl + lane;
+      for (; r + 15 * step < rows; r += 16 * step) {      // 16 loads in flight per thread
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = in[(int64_t)(r + u * step) * width + e];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+          s0 += (double)v[u]; s1 += (double)v[u + 1]; s2 += (double)v[u + 2]; s3 += (double)v[u + 3];
+        }
+      }
       for (; r + 3 * step < rows; r += 4 * step) {
         s0 += (double)in[(int64_t)r * width + e];
         s1 += (double)in[(int64_t)(r + step) * width + e];
@@ -114,7 +128,7 @@ static inline int collapse_fin_launch(const float* partials, int rows, int width
     return SEGMI_EINVAL;
   }
   const unsigned ticket = g_fin_next.fetch_add(1) % kFinTickets;
-  hipLaunchKernelGGL(collapse_fin_kernel<Fin>, fin_blocks(rows), 256,
+  hipLaunchKernelGGL(collapse_fin_kernel<Fin>, fin_blocks(rows, width), 256,
                      width <= kFinLdsWidth ? (size_t)width * sizeof(double) : 0,
                      st, partials, rows, width, scratch, ticket, fin);
   SEGMI_LAUNCH_CHECK(what);
