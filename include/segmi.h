@@ -159,9 +159,12 @@ int segmi_dice_chunks(const segmi_act* logits);
 int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labels,
                            float* partials, float* coef, float* loss, float smooth_nr,
                            float smooth_dr, void* stream);
+/* backward: dlogits = grad_scale * dLoss/dlogits.  bias_grad (nullable, f32[k]): also the channel
+ * sums of dlogits -- the bias gradient of the layer that produced the logits -- folded into the same
+ * pass; it needs `scratch` = the forward's `partials` buffer (free again after the forward). */
 int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labels,
                            const float* coef, float grad_scale, const segmi_act* dlogits,
-                           void* stream);
+                           float* scratch, float* bias_grad, void* stream);
 
 /* torch.optim.Adam / SGD semantics over one flat f32 arena, monai_unet.py:292-304,346.
  * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */

@@ -73,7 +73,7 @@ SIGNATURES = {
     "segmi_ndhwc_to_nchw": (_i, [_i, _AP, _P, _P]),
     "segmi_dice_chunks": (_i, [_AP]),
     "segmi_softmax_dice_fwd": (_i, [_i, _AP, _P, _P, _P, _P, _f, _f, _P]),
-    "segmi_softmax_dice_bwd": (_i, [_i, _AP, _P, _P, _f, _AP, _P]),
+    "segmi_softmax_dice_bwd": (_i, [_i, _AP, _P, _P, _f, _AP, _P, _P, _P]),
     "segmi_adam_step": (_i, [_P, _P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i64, _f, _P]),
     "segmi_sgd_step": (_i, [_P, _P, _P, _i64, _f, _f, _f, _i, _f, _P]),
     "segmi_adabelief_step": (_i, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i, _i64, _f, _P]),

@@ -20,6 +20,7 @@ struct DiceParams {
   int64_t vox;       // voxels per batch item
   int chunks;
   float grad_scale;
+  float* bias_part;  // [n * chunks][k] per-workgroup channel sums of the written gradient (nullable)
 };
 
 template <typename T, int KMAX>
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
   const T* lg = (const T*)p.logits + (int64_t)n * p.vox * p.ld;
   T* dl = (T*)p.dlogits + (int64_t)n * p.vox * p.ldd;
   const float* lb = p.labels + (int64_t)n * p.vox;
+  float gsum[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) gsum[j] = 0.f;
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float x[KMAX];
     load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
@@ -175,13 +179,35 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) g4[e] = (j + e < KMAX) ? p.grad_scale * x[j + e] * (dp[j + e] - dot) : 0.f;
           store4<T>(o + j, g4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < KMAX) gsum[j + e] += g4[e];
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
-        if (j < p.k) Elem<T>::st(o + j, p.grad_scale * x[j] * (dp[j] - dot));
+        if (j < p.k) {
+          const float gv = p.grad_scale * x[j] * (dp[j] - dot);
+          Elem<T>::st(o + j, gv);
+          gsum[j] += gv;
+        }
     }
+  }
+  // bias gradient of the layer that produced the logits = channel sums of dlogits: folded here so
+  // the 537 MB tensor is not read once more for it (fixed-order: wave butterfly, then 4 waves)
+  if (p.bias_part) {
+    __shared__ float bsum[4][KMAX];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      const float s = wave_sum(gsum[j]);
+      if (lane == 0) bsum[wave][j] = s;
+    }
+    __syncthreads();
+    if (tid < p.k)
+      p.bias_part[((int64_t)n * p.chunks + chunk) * p.k + tid] =
+          (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
   }
 }
 
@@ -307,9 +333,17 @@ int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labe
                              fin, "softmax_dice_fwd(finalize)");
 }
 
+struct ChanSumFin {   // sums: [k] channel sums
+  int k;
+  float* db;
+  __device__ void operator()(const double* sums, double*) const {
+    for (int ch = threadIdx.x; ch < k; ch += 256) db[ch] = (float)sums[ch];
+  }
+};
+
 int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labels,
                            const float* coef, float grad_scale, const segmi_act* dlogits,
-                           void* stream) {
+                           float* scratch, float* bias_grad, void* stream) {
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "softmax_dice_bwd: bad dtype");
   SEGMI_CHECK_ARG(act_ok(logits) && act_ok(dlogits) && labels && coef &&
                       logits->n == dlogits->n && logits->d == dlogits->d &&
@@ -321,9 +355,16 @@ int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labe
   p.vox = (int64_t)logits->d * logits->h * logits->w;
   p.chunks = dice_real_chunks(logits);
   p.grad_scale = grad_scale;
+  SEGMI_CHECK_ARG(!bias_grad || scratch, "softmax_dice_bwd: bias_grad needs the scratch buffer");
+  p.bias_part = bias_grad ? scratch : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == SEGMI_F32 ? dice_dispatch<float>(false, p, st)
-                            : dice_dispatch<bf16_t>(false, p, st);
+  const int rc = dtype == SEGMI_F32 ? dice_dispatch<float>(false, p, st)
+                                    : dice_dispatch<bf16_t>(false, p, st);
+  if (rc || !bias_grad) return rc;
+  const int rows = p.n * p.chunks;
+  const ChanSumFin fin{p.k, bias_grad};
+  return collapse_fin_launch(scratch, rows, p.k, fin_scratch(scratch, rows, p.k), st, fin,
+                             "softmax_dice_bwd(bias)");
 }
 
 int segmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -271,10 +271,13 @@ def softmax_dice_fwd(logits, labels, partials, coef, loss, smooth_nr=1e-5, smoot
                                      smooth_dr, _stream()), "softmax_dice_fwd")
 
 
-def softmax_dice_bwd(logits, labels, coef, grad_scale, dlogits) -> None:
+def softmax_dice_bwd(logits, labels, coef, grad_scale, dlogits, scratch=None, bias_grad=None) -> None:
+    """bias_grad (f32[K], optional): channel sums of dlogits, folded into the same pass; `scratch`
+    is then the forward's partials buffer."""
     a, b = act(logits), act(dlogits)
     check(lib.segmi_softmax_dice_bwd(dtype_code(logits), C.byref(a), _ptr(labels), _ptr(coef),
-                                     float(grad_scale), C.byref(b), _stream()),
+                                     float(grad_scale), C.byref(b), _ptr(scratch), _ptr(bias_grad),
+                                     _stream()),
           "softmax_dice_bwd")
 
 

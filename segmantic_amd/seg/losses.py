@@ -55,10 +55,14 @@ def dice_forward(state: _DiceState, logits_ndhwc: torch.Tensor, labels: torch.Te
 
 
 def dice_backward(state: _DiceState, logits_ndhwc: torch.Tensor, grad_scale: float = 1.0,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None,
+                  bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``bias_grad`` (f32[K]): also receives sum_voxels dlogits, i.e. the bias gradient of the conv
+    that produced the logits (saves that layer a pass over the gradient tensor)."""
     if out is None or out.shape != logits_ndhwc.shape or out.dtype != logits_ndhwc.dtype:
         out = torch.empty_like(logits_ndhwc)
-    ops.softmax_dice_bwd(logits_ndhwc, state.labels, state.coef, grad_scale, out)
+    ops.softmax_dice_bwd(logits_ndhwc, state.labels, state.coef, grad_scale, out,
+                         scratch=state.partials if bias_grad is not None else None, bias_grad=bias_grad)
     return out
 
 

@@ -214,10 +214,11 @@ class Net(torch.nn.Module):
             st = self.loss_function._state
             loss = dice_forward(st, logits, labels, self.loss_function.smooth_nr,
                                 self.loss_function.smooth_dr)
-            dlogits = dice_backward(st, logits, 1.0, eng._buf("dlogits", logits.shape))
+            dlogits = dice_backward(st, logits, 1.0, eng._buf("dlogits", logits.shape),
+                                    bias_grad=eng.top_bias_grad())
             if self._gsync is not None:
                 self._gsync.start()
-            eng.backward(dlogits)
+            eng.backward(dlogits, top_bias_done=True)
             scale = 1.0
             if self._gsync is not None:
                 self._gsync.finish()

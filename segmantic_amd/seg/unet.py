@@ -578,7 +578,7 @@ class UNetEngine:
                 self._bn_bwd(bn, g, r, dr)
             else:
                 dr = g
-            self._wgrad(conv, xin, dr, need_bias=bn is None)
+            self._wgrad(conv, xin, dr, need_bias=bn is None and conv is not self._top_bias_conv)
             if i > 0:
                 da = self._buf(f"{pre}.da{i - 1}", xin.shape)
                 self._dgrad(conv, dr, da)
@@ -741,12 +741,21 @@ class UNetEngine:
         self._level_fwd(self.levels, xin, logits, train)
         return logits
 
-    def backward(self, dlogits: torch.Tensor) -> None:
+    def top_bias_grad(self) -> torch.Tensor:
+        """Gradient slot of the bias of the conv that produces the logits (f32[K]): a loss kernel
+        that already walks dlogits can fill it (``backward(..., top_bias_done=True)``)."""
+        return self.levels["upru"]["units"][-1][0].gb
+
+    def backward(self, dlogits: torch.Tensor, top_bias_done: bool = False) -> None:
         """dlogits NDHWC (compute dtype).  Fills the flat gradient arena (overwrites)."""
         if not self._saved:
             raise RuntimeError("backward() needs a preceding training-mode forward()")
+        self._top_bias_conv = self.levels["upru"]["units"][-1][0] if top_bias_done else None
         self._level_bwd(self.levels, dlogits)
+        self._top_bias_conv = None
         self._join_side()
+
+    _top_bias_conv = None
 
     # ------------------------------------------------------------------ live kernel timing
     # bench.py sets `timed = {"<conv prefix>:<fwd|wgrad|dgrad>"}`; the matching C-ABI call is

@@ -427,6 +427,14 @@ def test_softmax_dice(dtype, k):
     torch.cuda.synchronize()
     assert abs(float(out.cpu()) - float(loss)) < 1e-6 * max(1.0, abs(float(loss)))  # loss within 1e-4 rel gate
     assert relerr(from_ndhwc(dl), lq.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    # the same pass can also deliver sum_voxels dlogits (bias gradient of the logits' producer)
+    dl2 = torch.empty_like(ld)
+    db = torch.empty(k, device=DEV)
+    ops.softmax_dice_bwd(ld, labd, coef, 1.0, dl2, scratch=part, bias_grad=db)
+    torch.cuda.synchronize()
+    assert torch.equal(dl2, dl)
+    ref_db = lq.grad.double().sum((0, 2, 3, 4))
+    assert float((db.cpu().double() - ref_db).abs().max()) < 1e-5 + (1e-4 if dtype == torch.float32 else 1e-2) * float(lq.grad.abs().sum() / k)
 
 
 def test_adam_sgd_match_torch():
