@@ -68,7 +68,8 @@ __device__ __forceinline__ void softmax_inplace(int k, float (&v)[KMAX]) {
   for (int j = 0; j < KMAX; ++j) if (j < k) v[j] *= inv;
 }
 
-template <typename T, int KMAX>
+// FULL: k == KMAX (16 / 32 / 64 labels): every per-channel predicate folds away at compile time
+template <typename T, int KMAX, bool FULL>
 __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
   __shared__ float red[4][3 * KMAX];
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -82,12 +83,12 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
   for (int j = 0; j < KMAX; ++j) si[j] = sp[j] = stt[j] = 0.f;
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float x[KMAX];
-    load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
-    softmax_inplace<KMAX, sizeof(T) == 2>(p.k, x);
+    load_logits<T, KMAX>(lg + v * p.ld, FULL ? KMAX : p.k, x);
+    softmax_inplace<KMAX, sizeof(T) == 2>(FULL ? KMAX : p.k, x);
     const int lab = (int)lb[v];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
-      if (j < p.k) {
+      if (FULL || j < p.k) {
         sp[j] += x[j];
         if (j == lab) { si[j] += x[j]; stt[j] += 1.f; }
       }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
   }
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
-    if (j < p.k) {
+    if (FULL || j < p.k) {
       const float a = wave_sum(si[j]), b = wave_sum(sp[j]), c = wave_sum(stt[j]);
       if (lane == 0) { red[wave][j] = a; red[wave][KMAX + j] = b; red[wave][2 * KMAX + j] = c; }
     }
@@ -141,7 +142,7 @@ struct DiceFin {
   }
 };
 
-template <typename T, int KMAX>
+template <typename T, int KMAX, bool FULL>
 __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
   __shared__ float cf[2 * KMAX];
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -158,23 +159,23 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
   for (int j = 0; j < KMAX; ++j) gsum[j] = 0.f;
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float x[KMAX];
-    load_logits<T, KMAX>(lg + v * p.ld, p.k, x);
-    softmax_inplace<KMAX, sizeof(T) == 2>(p.k, x);
+    load_logits<T, KMAX>(lg + v * p.ld, FULL ? KMAX : p.k, x);
+    softmax_inplace<KMAX, sizeof(T) == 2>(FULL ? KMAX : p.k, x);
     const int lab = (int)lb[v];
     float dot = 0.f;
     float dp[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
-      if (j < p.k) {
+      if (FULL || j < p.k) {
         dp[j] = cf[KMAX + j] + (j == lab ? cf[j] : 0.f);
         dot = fmaf(x[j], dp[j], dot);
       }
     }
     T* o = dl + v * p.ldd;
-    if (p.k % 4 == 0 && ((uintptr_t)o % (4 * sizeof(T))) == 0) {
+    if ((FULL || p.k % 4 == 0) && ((uintptr_t)o % (4 * sizeof(T))) == 0) {
 #pragma unroll
       for (int j = 0; j < KMAX; j += 4) {
-        if (j < p.k) {
+        if (FULL || j < p.k) {
           f32x4 g4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) g4[e] = (j + e < KMAX) ? p.grad_scale * x[j + e] * (dp[j + e] - dot) : 0.f;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
     } else {
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
-        if (j < p.k) {
+        if (FULL || j < p.k) {
           const float gv = p.grad_scale * x[j] * (dp[j] - dot);
           Elem<T>::st(o + j, gv);
           gsum[j] += gv;
@@ -283,8 +284,13 @@ static int dice_dispatch(bool fwd, const DiceParams& p, hipStream_t st) {
   dim3 grid(p.chunks, p.n);
 #define DICE_K(KM)                                                                       \
   do {                                                                                   \
-    if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM>), grid, 256, 0, st, p);          \
-    else hipLaunchKernelGGL((dice_bwd_kernel<T, KM>), grid, 256, 0, st, p);              \
+    if (p.k == KM) {                                                                     \
+      if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM, true>), grid, 256, 0, st, p);  \
+      else hipLaunchKernelGGL((dice_bwd_kernel<T, KM, true>), grid, 256, 0, st, p);      \
+    } else {                                                                             \
+      if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM, false>), grid, 256, 0, st, p); \
+      else hipLaunchKernelGGL((dice_bwd_kernel<T, KM, false>), grid, 256, 0, st, p);     \
+    }                                                                                    \
   } while (0)
   if (p.k <= 4) DICE_K(4);
   else if (p.k <= 16) DICE_K(16);
