@@ -172,7 +172,8 @@ class Net(torch.nn.Module):
         compute dtype (the sliding-window prediction cache).  Returns False when the module is in
         training mode or the buffer does not fit, so the caller falls back to ``forward``."""
         eng = self._engine_for(x)
-        if self.training or out_ndhwc.dtype != eng.dtype or not out_ndhwc.is_contiguous():
+        if (self.training or out_ndhwc.dtype != eng.dtype or not out_ndhwc.is_contiguous()
+                or eng.kpad != eng.net.out_channels):
             return False
         with torch.cuda.device(eng.device):
             eng.forward(x, train=False, out=out_ndhwc)
@@ -214,7 +215,7 @@ class Net(torch.nn.Module):
             st = self.loss_function._state
             loss = dice_forward(st, logits, labels, self.loss_function.smooth_nr,
                                 self.loss_function.smooth_dr)
-            dlogits = dice_backward(st, logits, 1.0, eng._buf("dlogits", logits.shape),
+            dlogits = dice_backward(st, logits, 1.0, eng.dlogits_buffer(logits),
                                     bias_grad=eng.top_bias_grad())
             if self._gsync is not None:
                 self._gsync.start()

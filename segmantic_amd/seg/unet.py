@@ -275,35 +275,66 @@ class UNetEngine:
         self._build_plan()
 
     # ------------------------------------------------------------------ arenas
+    # Channel padding of the class axis.  The MFMA kernels want channel counts that are multiples
+    # of 16; num_classes rarely is (2..10 tissues are typical).  Instead of falling back to the
+    # generic direct kernels for the three full-resolution layers that carry K channels (4x slower
+    # measured at K = 3), the engine stores those layers with kpad = ceil16(K) channels: extra
+    # weights / biases / BN parameters are zero and stay zero (their gradients are exactly 0), extra
+    # activations are exactly 0, and softmax / Dice / argmax / blend read only the first K channels
+    # of the kpad-strided tensors.  nn.Parameters and checkpoints keep MONAI's shapes: they are
+    # (strided) views of the padded arena slots.
+    _PADDED = {"model.2.0.conv.weight": (1,), "model.2.0.conv.bias": (0,),
+               "model.2.0.adn.N.weight": (0,), "model.2.0.adn.N.bias": (0,),
+               "model.2.1.conv.unit0.conv.weight": (0, 1), "model.2.1.conv.unit0.conv.bias": (0,)}
+    _PADDED_BUFFERS = ("model.2.0.adn.N.running_mean", "model.2.0.adn.N.running_var")
+
+    def _arena_layout(self, name: str, p) -> Tuple[tuple, tuple]:
+        """(shape of the arena slot, index that selects the nn.Parameter's view of it).
+
+        spatial_dims=2: a [Co, Ci, k, k] kernel lives in the centre plane of a [Co, Ci, k, k, k] one
+        (zeros elsewhere) so the 3-D kernels compute the 2-D convolution on a depth-1 volume: the
+        off-centre taps only ever meet the zero padding, their weights and gradients stay exactly 0."""
+        shape = list(p.shape)
+        index = [slice(None)] * len(shape)
+        for d in self._PADDED.get(name, ()) if self.kpad != self.net.out_channels else ():
+            index[d] = slice(0, shape[d])
+            shape[d] = self.kpad
+        if self.net.dimensions == 2 and p.dim() == 4:
+            shape = shape[:2] + [shape[2]] + shape[2:]
+            index = index[:2] + [shape[2] // 2] + index[2:]
+        return tuple(shape), tuple(index)
+
     def _build_arena(self):
+        k = self.net.out_channels
+        self.kpad = k if k % 16 == 0 else (k + 15) // 16 * 16
         named = list(self.net.named_parameters())
-        total = sum(int(math.prod(self._arena_shape(p))) for _, p in named)
-        self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        layout = {name: self._arena_layout(name, p) for name, p in named}
+        total = sum(int(math.prod(layout[name][0])) for name, _ in named)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         self._pviews: Dict[str, torch.Tensor] = {}
         self._gviews: Dict[str, torch.Tensor] = {}
+        self._galias: Dict[str, torch.Tensor] = {}
         self.param_offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
         self._palias: Dict[str, torch.Tensor] = {}
         for name, p in named:
-            shape = self._arena_shape(p)
+            shape, index = layout[name]
             n = int(math.prod(shape))
             view = self.flat[off:off + n].view(shape)
             g = self.flat_grad[off:off + n].view(shape)
-            alias, galias = view, g
-            if len(shape) != p.dim():          # 2-D kernel embedded in the kd = centre plane
-                view.zero_()
-                mid = shape[2] // 2
-                alias, galias = view[:, :, mid], g[:, :, mid]
+            alias, galias = view[index], g[index]
             alias.copy_(p.data.to(self.device, torch.float32))
             p.data = alias                     # nn.Parameter now aliases the arena
             p.grad = galias
             self._pviews[name] = view
             self._gviews[name] = g
             self._palias[name] = alias
+            self._galias[name] = galias
             self.param_offsets[name] = (off, n)
             off += n
         self._bviews: Dict[str, torch.Tensor] = {}
+        self._balias: Dict[str, torch.Tensor] = {}
         # the int64 ``num_batches_tracked`` counters share one arena: one add per training step
         nbt = [n for n, _ in self.net.named_buffers() if n.endswith("num_batches_tracked")]
         self._nbt_flat = torch.zeros(max(len(nbt), 1), dtype=torch.int64, device=self.device)
@@ -312,20 +343,19 @@ class UNetEngine:
                 view = self._nbt_flat[nbt.index(name)]
                 view.copy_(b.data.to(self.device))
                 b.data = view
+                full = view
+            elif name in self._PADDED_BUFFERS and self.kpad != k:
+                full = torch.zeros(self.kpad, dtype=b.dtype, device=self.device)
+                if name.endswith("running_var"):
+                    full.fill_(1.0)
+                full[:k].copy_(b.data.to(self.device))
+                b.data = full[:k]
             else:
                 b.data = b.data.to(self.device)
-            self._bviews[name] = b.data
+                full = b.data
+            self._bviews[name] = full
+            self._balias[name] = b.data
         self.num_params = total
-
-    def _arena_shape(self, p) -> tuple:
-        """Shape a parameter takes in the arena.  spatial_dims=2: a [Co, Ci, k, k] kernel lives in
-        the centre plane of a [Co, Ci, k, k, k] one (zeros elsewhere) so the 3-D kernels compute the
-        2-D convolution on a depth-1 volume: the off-centre taps only ever meet the zero padding,
-        their weights and gradients stay exactly 0, and the nn.Parameter / checkpoint keep MONAI's
-        2-D shape (a strided view of the centre plane)."""
-        if self.net.dimensions == 2 and p.dim() == 4:
-            return tuple(p.shape[:2]) + (p.shape[2],) + tuple(p.shape[2:])
-        return tuple(p.shape)
 
     def rebind(self):
         """Re-alias parameters after an external ``.to()`` / ``load_state_dict`` replaced data."""
@@ -334,10 +364,9 @@ class UNetEngine:
             if p.data.data_ptr() != alias.data_ptr():
                 alias.copy_(p.data.to(self.device, torch.float32))
                 p.data = alias
-            gv = self._gviews[name]
-            p.grad = gv if gv.dim() == p.dim() else gv[:, :, gv.shape[2] // 2]
+            p.grad = self._galias[name]
         for name, b in self.net.named_buffers():
-            tgt = self._bviews[name]
+            tgt = self._balias[name]
             if b.data.data_ptr() != tgt.data_ptr():
                 tgt.copy_(b.data.to(self.device))
                 b.data = tgt
@@ -376,7 +405,7 @@ class UNetEngine:
     # ------------------------------------------------------------------ plan
     def _build_plan(self):
         chs, sts = list(self.net.channels), list(self.net.strides)
-        self.levels = self._make_level("", self.net.in_channels, self.net.out_channels, chs, sts, True)
+        self.levels = self._make_level("", self.net.in_channels, self.kpad, chs, sts, True)
 
     def _make_ru(self, prefix, cin, cout, stride, subunits, last_conv_only=False):
         units = []
@@ -726,10 +755,13 @@ class UNetEngine:
         train = self.training if train is None else train
         xin = self._prep_input(x)
         n, d, h, w, _ = xin.shape
-        shape = (n, d, h, w, self.net.out_channels)
+        k = self.net.out_channels
+        shape = (n, d, h, w, self.kpad)
         if out is not None:
             if train:
                 raise ValueError("forward(out=...) is an inference-only path")
+            if self.kpad != k:
+                raise ValueError("forward(out=...) needs a class count that is a multiple of 16")
             if tuple(out.shape) != shape or out.dtype != self.dtype or not out.is_contiguous():
                 raise ValueError(f"out must be a contiguous {shape} {self.dtype} tensor")
             logits = out
@@ -739,7 +771,17 @@ class UNetEngine:
             self._saved.clear()
             self._nbt_flat += 1        # every BatchNorm runs exactly once per training forward
         self._level_fwd(self.levels, xin, logits, train)
-        return logits
+        return logits if self.kpad == k else logits[..., :k]     # the K real classes (view, ld = kpad)
+
+    def dlogits_buffer(self, logits: torch.Tensor) -> torch.Tensor:
+        """Gradient buffer matching ``forward``'s result: the first K channels of a zero-initialised
+        kpad-channel tensor (a loss kernel writes the K real channels, the padding stays 0)."""
+        n, d, h, w, k = logits.shape
+        full = self._bufs.get("dlogits")
+        if full is None or tuple(full.shape) != (n, d, h, w, self.kpad) or full.dtype != self.dtype:
+            full = torch.zeros((n, d, h, w, self.kpad), dtype=self.dtype, device=self.device)
+            self._bufs["dlogits"] = full
+        return full if self.kpad == k else full[..., :k]
 
     def top_bias_grad(self) -> torch.Tensor:
         """Gradient slot of the bias of the conv that produces the logits (f32[K]): a loss kernel
@@ -751,6 +793,15 @@ class UNetEngine:
         if not self._saved:
             raise RuntimeError("backward() needs a preceding training-mode forward()")
         self._top_bias_conv = self.levels["upru"]["units"][-1][0] if top_bias_done else None
+        if dlogits.shape[4] != self.kpad:       # K real classes -> the padded gradient tensor
+            full = self._bufs.get("dlogits")
+            own = (full is not None and full.data_ptr() == dlogits.data_ptr()
+                   and tuple(full.shape[:4]) == tuple(dlogits.shape[:4]) and dlogits.stride(3) == self.kpad)
+            if not own:
+                full = self.dlogits_buffer(dlogits)
+                full = self._bufs["dlogits"]
+                full[..., :dlogits.shape[4]].copy_(dlogits)
+            dlogits = full
         self._level_bwd(self.levels, dlogits)
         self._top_bias_conv = None
         self._join_side()

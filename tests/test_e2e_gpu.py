@@ -37,7 +37,7 @@ def test_hip_path_reproduces_committed_goldens(gold):
     net.train()
     res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
     torch.cuda.synchronize()
-    logits = net._engine._bufs["logits.t"].float().cpu().permute(0, 4, 1, 2, 3).numpy()
+    logits = net._engine._bufs["logits.t"][..., :net.num_classes].float().cpu().permute(0, 4, 1, 2, 3).numpy()
     g = gold["tiny_logits"]
     assert np.abs(logits - g).max() / np.abs(g).max() < 2e-4            # 1e-3 gate
     assert abs(float(res["loss"].cpu()) - float(gold["tiny_loss"])) < 1e-4 * float(gold["tiny_loss"])
@@ -343,14 +343,14 @@ def test_spatial_dims_2_matches_oracle_and_trains():
     loss_ref.backward()
     res = net.training_step({"image": x.to(DEV), "label": lab.to(DEV)})
     torch.cuda.synchronize()
-    y = net._engine._bufs["logits.t"].float().cpu().permute(0, 4, 1, 2, 3).squeeze(2)
+    y = net._engine._bufs["logits.t"][..., :net.num_classes].float().cpu().permute(0, 4, 1, 2, 3).squeeze(2)
     assert float((y - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 2e-4
     assert abs(float(res["loss"].cpu()) - float(loss_ref)) < 1e-4 * float(loss_ref)
     # gradients landed in the 2-D views (centre plane of the embedded kernels); off-centre taps stay 0
     sd_ref = dict(ref.named_parameters())
     for key in ("model.0.conv.unit0.conv.weight", "model.2.0.conv.weight", "model.1.submodule.1.submodule.residual.weight"):
         gw = net._engine._gviews[key]
-        g2 = gw if gw.dim() == 4 else gw[:, :, gw.shape[2] // 2]
+        g2 = net._engine._galias[key]
         gr = sd_ref[key].grad
         assert float((g2.cpu() - gr).abs().max()) < 2e-3 * float(gr.abs().max()) + 1e-7, key
         if gw.dim() == 5 and gw.shape[2] == 3:
@@ -363,3 +363,54 @@ def test_spatial_dims_2_matches_oracle_and_trains():
         sw = sliding_window_inference(x[:1].to(DEV), (16, 16), 4, net, 0.5, return_labels=True)
         assert sw.logits.shape == (1, 3, 32, 48) and sw.labels.shape == (1, 1, 32, 48)
     assert tuple(net.state_dict()["_model.model.0.conv.unit0.conv.weight"].shape) == (16, 1, 3, 3)
+
+
+@pytest.mark.parametrize("K", [3, 20])
+def test_class_count_not_a_multiple_of_16_runs_padded_on_mfma(K):
+    """num_classes = 3 / 20: the K-channel layers are stored with 16 / 32 channels (zeros) so they
+    take the MFMA kernels; logits, loss and every gradient still match the oracle, parameters and
+    checkpoints keep MONAI's shapes, and the padding stays exactly zero through an optimiser step."""
+    ref, net = pair(K, (16, 32, 64), (2, 2))
+    img, lab = synthetic_batch(2, 32, K, seed=9)
+    ref.train(); net.train()
+    y_ref = ref(img)
+    loss_ref = ref_dice_loss(y_ref, lab)
+    loss_ref.backward()
+    res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+    torch.cuda.synchronize()
+    eng = net._engine
+    assert eng.kpad == (16 if K == 3 else 32)
+    full = eng._bufs["logits.t"].float().cpu()
+    assert full.shape[-1] == eng.kpad and float(full[..., K:].abs().max()) == 0.0     # padded classes are 0
+    y = full[..., :K].permute(0, 4, 1, 2, 3)
+    assert float((y - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 2e-4
+    assert abs(float(res["loss"].detach().cpu()) - float(loss_ref.detach())) < 1e-4 * float(loss_ref.detach())
+    sd = net._model.state_dict()
+    assert tuple(sd["model.2.1.conv.unit0.conv.weight"].shape) == (K, K, 3, 3, 3)
+    assert tuple(sd["model.2.0.conv.weight"].shape)[1] == K and tuple(sd["model.2.0.adn.N.running_var"].shape) == (K,)
+    # gradients of the padded layers (compared before the step overwrote nothing: grads persist)
+    rp = dict(ref.named_parameters())
+    for key in ("model.2.1.conv.unit0.conv.weight", "model.2.1.conv.unit0.conv.bias", "model.2.0.conv.weight",
+                "model.2.0.adn.N.weight", "model.0.conv.unit1.conv.weight"):
+        g = eng._galias[key].cpu()
+        gr = rp[key].grad
+        assert g.shape == gr.shape
+        assert float((g - gr).abs().max()) < 3e-3 * float(gr.abs().max()) + 2e-6 * float(
+            max(t.grad.abs().max() for t in rp.values())), key
+    # padding of weights and gradients is exactly zero, also after the Adam step that just ran
+    for key in ("model.2.1.conv.unit0.conv.weight", "model.2.0.conv.weight", "model.2.0.conv.bias"):
+        wv, gv = eng._pviews[key], eng._gviews[key]
+        mask = torch.ones_like(wv, dtype=torch.bool)
+        mask[eng._arena_layout(key, rp[key])[1]] = False
+        assert float(wv[mask].abs().max()) == 0.0 and float(gv[mask].abs().max()) == 0.0, key
+    # eval + sliding window + a reloaded checkpoint give the same labels
+    net.eval()
+    with torch.no_grad():
+        a = sliding_window_inference(img[:1].to(DEV), (16, 16, 16), 4, net, 0.5, return_labels=True)
+    assert a.logits.shape == (1, K, 32, 32, 32) and int(a.labels.max()) < K
+    net2 = Net(num_classes=K, num_channels=1, channels=(16, 32, 64), strides=(2, 2))
+    net2.load_state_dict(net.state_dict())
+    net2.to(DEV).eval()
+    with torch.no_grad():
+        b = sliding_window_inference(img[:1].to(DEV), (16, 16, 16), 4, net2, 0.5, return_labels=True)
+    assert torch.equal(a.labels, b.labels) and torch.equal(a.logits, b.logits)
