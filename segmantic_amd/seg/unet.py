@@ -47,7 +47,12 @@ def _conv_params(cin: int, cout: int, k: int, dims: int, transposed: bool) -> _B
     return m
 
 
-def _adn_params(ch: int) -> _Box:
+# MONAI activation names this build maps onto its PReLU-shaped kernels: y = x > 0 ? x : slope * x
+# with a learnable scalar slope (PRELU, the reference default) or a fixed one.
+FIXED_SLOPE = {"RELU": 0.0, "LEAKYRELU": 0.01}
+
+
+def _adn_params(ch: int, act: str = "PRELU") -> _Box:
     adn = _Box()
     n = _Box()
     n.weight = nn.Parameter(torch.ones(ch))
@@ -55,28 +60,29 @@ def _adn_params(ch: int) -> _Box:
     n.register_buffer("running_mean", torch.zeros(ch))
     n.register_buffer("running_var", torch.ones(ch))
     n.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
-    a = _Box()
-    a.weight = nn.Parameter(torch.full((1,), 0.25))
     adn.add_module("N", n)
-    adn.add_module("A", a)
+    if act == "PRELU":                       # torch.nn.PReLU(): one learnable slope, init 0.25
+        a = _Box()
+        a.weight = nn.Parameter(torch.full((1,), 0.25))
+        adn.add_module("A", a)               # ReLU / LeakyReLU have no parameters (as in MONAI's ADN)
     return adn
 
 
-def _convolution_params(cin, cout, k, dims, conv_only=False, transposed=False) -> _Box:
+def _convolution_params(cin, cout, k, dims, conv_only=False, transposed=False, act="PRELU") -> _Box:
     m = _Box()
     m.add_module("conv", _conv_params(cin, cout, k, dims, transposed))
     if not conv_only:
-        m.add_module("adn", _adn_params(cout))
+        m.add_module("adn", _adn_params(cout, act))
     return m
 
 
-def _residual_unit_params(cin, cout, stride, k, dims, subunits, last_conv_only=False) -> _Box:
+def _residual_unit_params(cin, cout, stride, k, dims, subunits, last_conv_only=False, act="PRELU") -> _Box:
     m = _Box()
     conv = _Box()
     sc = cin
     for su in range(max(1, subunits)):
         conv_only = last_conv_only and su == max(1, subunits) - 1
-        conv.add_module(f"unit{su:d}", _convolution_params(sc, cout, k, dims, conv_only))
+        conv.add_module(f"unit{su:d}", _convolution_params(sc, cout, k, dims, conv_only, act=act))
         sc = cout
     m.add_module("conv", conv)
     if stride != 1 or cin != cout:
@@ -90,7 +96,7 @@ class UNetParams(nn.Module):
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int,
                  channels: Sequence[int], strides: Sequence[int], num_res_units: int = 2,
-                 kernel_size: int = 3):
+                 kernel_size: int = 3, act: str = "PRELU"):
         super().__init__()
         if len(channels) < 2:
             raise ValueError("the length of `channels` should be no less than 2.")
@@ -98,6 +104,10 @@ class UNetParams(nn.Module):
             raise ValueError("the length of `strides` should equal to `len(channels) - 1`.")
         if num_res_units < 1:
             raise ValueError("segmantic builds its UNet with num_res_units=2")
+        act = str(act).upper()
+        if act != "PRELU" and act not in FIXED_SLOPE:
+            raise NotImplementedError(f"segmantic_amd implements act in PRELU / RELU / LEAKYRELU, not {act}")
+        self.act = act
         self.dimensions = spatial_dims
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -112,14 +122,14 @@ class UNetParams(nn.Module):
                 sub = block(c, c, chs[1:], sts[1:], False)
                 upc = c * 2
             else:
-                sub = _residual_unit_params(c, chs[1], 1, k, d, nr)
+                sub = _residual_unit_params(c, chs[1], 1, k, d, nr, act=act)
                 upc = c + chs[1]
             skip = _Box()
             skip.add_module("submodule", sub)
             up = _Box()
-            up.add_module("0", _convolution_params(upc, outc, k, d, transposed=True))
-            up.add_module("1", _residual_unit_params(outc, outc, 1, k, d, 1, last_conv_only=is_top))
-            seq.add_module("0", _residual_unit_params(inc, c, s, k, d, nr))
+            up.add_module("0", _convolution_params(upc, outc, k, d, transposed=True, act=act))
+            up.add_module("1", _residual_unit_params(outc, outc, 1, k, d, 1, last_conv_only=is_top, act=act))
+            seq.add_module("0", _residual_unit_params(inc, c, s, k, d, nr, act=act))
             seq.add_module("1", skip)
             seq.add_module("2", up)
             return seq
@@ -221,10 +231,13 @@ class _BN:
         self.eng, self.prefix, self.c = eng, prefix, c
         self.gamma = eng.param(prefix + ".N.weight")
         self.beta = eng.param(prefix + ".N.bias")
-        self.alpha = eng.param(prefix + ".A.weight")
+        if eng.net.act == "PRELU":
+            self.alpha = eng.param(prefix + ".A.weight")
+        else:                                  # fixed slope: a device scalar the kernels read
+            self.alpha = eng.fixed_slope
         self.g_gamma = eng.grad(prefix + ".N.weight")
         self.g_beta = eng.grad(prefix + ".N.bias")
-        self.g_alpha = eng.grad(prefix + ".A.weight")
+        self.g_alpha = eng.grad(prefix + ".A.weight") if eng.net.act == "PRELU" else None
         self.rm = eng.buffer(prefix + ".N.running_mean")
         self.rv = eng.buffer(prefix + ".N.running_var")
         self.nbt = eng.buffer(prefix + ".N.num_batches_tracked")
@@ -271,6 +284,8 @@ class UNetEngine:
         self._scratch: Dict[str, torch.Tensor] = {}
         self._saved: Dict[str, torch.Tensor] = {}
         self.timings: Dict[str, list] = {}
+        self.fixed_slope = torch.full((1,), FIXED_SLOPE.get(params.act, 0.0), dtype=torch.float32,
+                                      device=self.device)
         self._build_arena()
         self._build_plan()
 

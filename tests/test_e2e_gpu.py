@@ -414,3 +414,35 @@ def test_class_count_not_a_multiple_of_16_runs_padded_on_mfma(K):
     with torch.no_grad():
         b = sliding_window_inference(img[:1].to(DEV), (16, 16, 16), 4, net2, 0.5, return_labels=True)
     assert torch.equal(a.labels, b.labels) and torch.equal(a.logits, b.logits)
+
+
+@pytest.mark.parametrize("act", ["RELU", "LEAKYRELU"])
+def test_fixed_slope_activations_match_oracle(act):
+    """`act` of the config schema: ReLU / LeakyReLU(0.01) run on the PReLU-shaped kernels with a fixed
+    slope; the ADN then has no `A.weight` parameter (MONAI key layout)."""
+    ref = deterministic_fill_(RefUNet(3, 1, 16, (16, 32, 64), (2, 2), act=act), 0)
+    net = Net(num_classes=16, num_channels=1, channels=(16, 32, 64), strides=(2, 2), act=act)
+    assert not any(".A." in k for k in net.state_dict())
+    net.load_state_dict({"_model." + k: v.clone() for k, v in ref.state_dict().items()})
+    net.to(DEV)
+    img, lab = synthetic_batch(2, 32, 16, seed=12)
+    net.eval(); ref.eval()            # eval first: the training step below changes the weights
+    with torch.no_grad():
+        ye, yr = net(img.to(DEV)).float().cpu(), ref(img)
+    assert float((ye - yr).abs().max() / yr.abs().max()) < 2e-4
+    ref.train(); net.train()
+    y_ref = ref(img)
+    loss_ref = ref_dice_loss(y_ref, lab)
+    loss_ref.backward()
+    res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+    torch.cuda.synchronize()
+    y = net._engine._bufs["logits.t"][..., :16].float().cpu().permute(0, 4, 1, 2, 3)
+    assert float((y - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 2e-4
+    assert abs(float(res["loss"].detach().cpu()) - float(loss_ref.detach())) < 1e-4 * float(loss_ref.detach())
+    rp = dict(ref.named_parameters())
+    gmax = max(float(t.grad.abs().max()) for t in rp.values())
+    for key in ("model.0.conv.unit0.conv.weight", "model.1.submodule.0.conv.unit1.conv.weight",
+                "model.2.0.adn.N.weight", "model.2.1.conv.unit0.conv.weight"):
+        g, gr = net._engine._galias[key].cpu(), rp[key].grad
+        # (kinked activations: pre-activations within rounding of 0 may take the other branch)
+        assert float((g - gr).abs().max()) < 1e-2 * float(gr.abs().max()) + 2e-6 * gmax, key
