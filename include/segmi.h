@@ -123,24 +123,28 @@ int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count
 int segmi_bn_eval_affine(int c, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, float eps,
                          float* scale, float* shift, void* stream);
-/* y = prelu(x*scale + shift) + residual   (alpha nullable -> identity, residual nullable) */
+/* y = prelu(drop(x*scale + shift)) + residual   (alpha nullable -> identity, residual nullable).
+ * MONAI ADN "NDA" dropout (the `dropout` key of the config, monai_unet.py:107,119): with
+ * dropout_p > 0 an element is kept iff hash(dropout_seed, logical NDHWC element index) >> 8 >=
+ * dropout_p * 2^24 and kept values are scaled by 1 / (1 - p); the mask is never stored, the two
+ * backward passes recompute it from the same seed.  dropout_p = 0 (eval, default): identity. */
 int segmi_bn_act_fwd(int dtype, const segmi_act* x, const segmi_act* y, const float* scale,
                      const float* shift, const float* prelu_alpha, const segmi_act* residual,
-                     void* stream);
-/* backward of y = prelu(bn(x)):  pass 1 reduces, finalize, pass 2 writes dx.
- * red_partials f32[rows][3][c]: sum dz, sum dz*xhat, sum dy*z*[z<=0]  (dz = dy*prelu'(z)) */
+                     float dropout_p, uint32_t dropout_seed, void* stream);
+/* backward of y = prelu(drop(bn(x))):  pass 1 reduces, finalize, pass 2 writes dx.
+ * red_partials f32[rows][3][c]: sum dz, sum dz*xhat, sum dy*z*[z<=0]  (dz = dy*prelu'(z)*mask) */
 int segmi_bn_act_bwd_rows(const segmi_act* x);
 int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
                             const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* prelu_alpha, float* red_partials,
-                            void* stream);
+                            float dropout_p, uint32_t dropout_seed, void* stream);
 int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double count,
                               const float* gamma, const float* invstd, float* dgamma,
                               float* dbeta, float* dalpha, float* coef, void* stream);
 int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
                            const segmi_act* dx, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const float* prelu_alpha,
-                           const float* coef, void* stream);
+                           const float* coef, float dropout_p, uint32_t dropout_seed, void* stream);
 
 /* elementwise helpers on NDHWC views */
 int segmi_add(int dtype, const segmi_act* a, const segmi_act* b, const segmi_act* out,

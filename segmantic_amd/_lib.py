@@ -62,11 +62,11 @@ SIGNATURES = {
     "segmi_bn_stats": (_i, [_i, _AP, _P, _P]),
     "segmi_bn_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P]),
     "segmi_bn_eval_affine": (_i, [_i, _P, _P, _P, _P, _f, _P, _P, _P]),
-    "segmi_bn_act_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _AP, _P]),
+    "segmi_bn_act_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _AP, _f, C.c_uint32, _P]),
     "segmi_bn_act_bwd_rows": (_i, [_AP]),
-    "segmi_bn_act_bwd_reduce": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P, _P]),
+    "segmi_bn_act_bwd_reduce": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
     "segmi_bn_act_bwd_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _P, _P, _P]),
-    "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _P]),
+    "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
     "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),
     "segmi_cast_copy": (_i, [_i, _AP, _i, _AP, _P]),
     "segmi_nchw_to_ndhwc": (_i, [_P, _i, _AP, _P]),

@@ -51,7 +51,19 @@ struct EwParams {
   const float* p0; const float* p1; const float* p2; const float* p3; const float* alpha;
   const float* coef;
   float* out_partials;
+  // ADN dropout between the norm and the activation (MONAI "NDA"): element kept iff
+  // hash(seed, logical NDHWC element index) >> 8 >= drop_thresh (= p * 2^24); kept values are
+  // scaled by drop_scale = 1 / (1 - p).  drop_thresh == 0: no dropout.  The mask is never stored:
+  // backward recomputes it from the same seed.
+  unsigned drop_thresh, drop_seed;
+  float drop_scale;
 };
+
+__device__ __forceinline__ float drop_mult(unsigned seed, int64_t elem, unsigned thresh, float scale) {
+  unsigned h = (unsigned)elem * 0x9E3779B1u ^ seed ^ ((unsigned)(elem >> 32) * 0x85EBCA77u);
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return (h >> 8) >= thresh ? scale : 0.f;
+}
 
 // ---------------------------------------------------------------- statistics
 template <typename T, int VEC>
@@ -195,6 +207,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(EwParams p) {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       float z = fmaf(a[k], prm[ch + k], prm[p.c + ch + k]);
+      if (p.drop_thresh) z *= drop_mult(p.drop_seed, v * p.c + ch + k, p.drop_thresh, p.drop_scale);
       if (has_alpha) z = z > 0.f ? z : alpha * z;
       a[k] = z;
     }
@@ -243,9 +256,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const float xh = (a[k] - mean[k]) * istd[k];
-        const float z = fmaf(xh, gam[k], bet[k]);
+        float z = fmaf(xh, gam[k], bet[k]);
+        float m = 1.f;
+        if (p.drop_thresh) {
+          m = drop_mult(p.drop_seed, v * p.c + my_cg * VEC + k, p.drop_thresh, p.drop_scale);
+          z *= m;
+        }
         float dz = d[k];
         if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[k], z, s2[k]); dz = alpha * d[k]; }
+        dz *= m;
         s0[k] += dz;
         s1[k] = fmaf(dz, xh, s1[k]);
       }
@@ -324,9 +343,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(EwParams p) {
     for (int k = 0; k < VEC; ++k) {
       const float is = prm[p.c + ch + k], gm = prm[2 * p.c + ch + k];
       const float xh = (a[k] - prm[ch + k]) * is;
-      const float z = fmaf(xh, gm, prm[3 * p.c + ch + k]);
+      float z = fmaf(xh, gm, prm[3 * p.c + ch + k]);
+      float m = 1.f;
+      if (p.drop_thresh) {
+        m = drop_mult(p.drop_seed, v * p.c + ch + k, p.drop_thresh, p.drop_scale);
+        z *= m;
+      }
       float dz = d[k];
       if (has_alpha && !(z > 0.f)) dz = alpha * d[k];
+      dz *= m;
       a[k] = gm * is * (dz - prm[4 * p.c + ch + k] - xh * prm[5 * p.c + ch + k]);
     }
     storev<T, VEC>(o + v * p.ldo + ch, a);
@@ -431,11 +456,14 @@ int segmi_bn_eval_affine(int c, const float* gamma, const float* beta,
 
 int segmi_bn_act_fwd(int dtype, const segmi_act* x, const segmi_act* y, const float* scale,
                      const float* shift, const float* prelu_alpha, const segmi_act* residual,
-                     void* stream) {
+                     float dropout_p, uint32_t dropout_seed, void* stream) {
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_fwd: bad dtype");
+  SEGMI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bn_act_fwd: dropout_p must be in [0, 1)");
   SEGMI_CHECK_ARG(act_ok(x) && act_ok(y) && same_shape(x, y), "bn_act_fwd: shape mismatch");
   if (residual) SEGMI_CHECK_ARG(act_ok(residual) && same_shape(x, residual), "bn_act_fwd: residual shape");
   EwParams p{};
+  p.drop_thresh = (unsigned)(dropout_p * 16777216.0f); p.drop_seed = dropout_seed;
+  p.drop_scale = 1.0f / (1.0f - dropout_p);
   p.x = x->data; p.o = y->data; p.r = residual ? residual->data : nullptr;
   p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld; p.ldo = y->ld;
   p.ldr = residual ? residual->ld : 0;
@@ -449,7 +477,7 @@ int segmi_bn_act_fwd(int dtype, const segmi_act* x, const segmi_act* y, const fl
 
 int segmi_add(int dtype, const segmi_act* a, const segmi_act* b, const segmi_act* out,
               void* stream) {
-  return segmi_bn_act_fwd(dtype, a, out, nullptr, nullptr, nullptr, b, stream);
+  return segmi_bn_act_fwd(dtype, a, out, nullptr, nullptr, nullptr, b, 0.f, 0u, stream);
 }
 
 int segmi_bn_act_bwd_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) + kReserveRows : 0; }
@@ -457,12 +485,15 @@ int segmi_bn_act_bwd_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) 
 int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
                             const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* prelu_alpha, float* red_partials,
-                            void* stream) {
+                            float dropout_p, uint32_t dropout_seed, void* stream) {
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_bwd_reduce: bad dtype");
+  SEGMI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bn_act_bwd_reduce: dropout_p must be in [0, 1)");
   SEGMI_CHECK_ARG(act_ok(dy) && act_ok(x) && same_shape(x, dy) && mean && invstd && red_partials,
                   "bn_act_bwd_reduce: bad arguments");
   SEGMI_CHECK_ARG(x->c <= 256, "bn_act_bwd_reduce: at most 256 channels per call");
   EwParams p{};
+  p.drop_thresh = (unsigned)(dropout_p * 16777216.0f); p.drop_seed = dropout_seed;
+  p.drop_scale = 1.0f / (1.0f - dropout_p);
   p.x = x->data; p.y = dy->data; p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld;
   p.ldy = dy->ld; p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha;
   p.out_partials = red_partials;
@@ -489,11 +520,14 @@ int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double
 int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
                            const segmi_act* dx, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const float* prelu_alpha,
-                           const float* coef, void* stream) {
+                           const float* coef, float dropout_p, uint32_t dropout_seed, void* stream) {
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_bwd_apply: bad dtype");
+  SEGMI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bn_act_bwd_apply: dropout_p must be in [0, 1)");
   SEGMI_CHECK_ARG(act_ok(dy) && act_ok(x) && act_ok(dx) && same_shape(x, dy) && same_shape(x, dx) &&
                       mean && invstd && coef, "bn_act_bwd_apply: bad arguments");
   EwParams p{};
+  p.drop_thresh = (unsigned)(dropout_p * 16777216.0f); p.drop_seed = dropout_seed;
+  p.drop_scale = 1.0f / (1.0f - dropout_p);
   p.x = x->data; p.y = dy->data; p.o = dx->data; p.nvox = act_voxels(x); p.c = x->c;
   p.ldx = x->ld; p.ldy = dy->ld; p.ldo = dx->ld;
   p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha; p.coef = coef;

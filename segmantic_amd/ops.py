@@ -194,11 +194,13 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift) ->
                                    _ptr(shift), _stream()), "bn_eval_affine")
 
 
-def bn_act_fwd(x, y, scale, shift, prelu_alpha=None, residual=None) -> None:
+def bn_act_fwd(x, y, scale, shift, prelu_alpha=None, residual=None, dropout=(0.0, 0)) -> None:
+    """dropout = (p, seed): ADN dropout between norm and activation (mask recomputed in backward)."""
     ax, ay = act(x), act(y)
     ar = act(residual) if residual is not None else None
     check(lib.segmi_bn_act_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(scale),
-                               _ptr(shift), _ptr(prelu_alpha), _ref(ar), _stream()),
+                               _ptr(shift), _ptr(prelu_alpha), _ref(ar), float(dropout[0]),
+                               int(dropout[1]) & 0xFFFFFFFF, _stream()),
           "bn_act_fwd")
 
 
@@ -207,11 +209,13 @@ def bn_act_bwd_rows(x) -> int:
     return int(lib.segmi_bn_act_bwd_rows(C.byref(ax)))
 
 
-def bn_act_bwd_reduce(dy, x, mean, invstd, gamma, beta, prelu_alpha, partials) -> None:
+def bn_act_bwd_reduce(dy, x, mean, invstd, gamma, beta, prelu_alpha, partials,
+                      dropout=(0.0, 0)) -> None:
     ady, ax = act(dy), act(x)
     check(lib.segmi_bn_act_bwd_reduce(dtype_code(x), C.byref(ady), C.byref(ax), _ptr(mean),
                                       _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(prelu_alpha),
-                                      _ptr(partials), _stream()), "bn_act_bwd_reduce")
+                                      _ptr(partials), float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF,
+                                      _stream()), "bn_act_bwd_reduce")
 
 
 def bn_act_bwd_finalize(partials, rows, c, count, gamma, invstd, dgamma, dbeta, dalpha,
@@ -221,11 +225,13 @@ def bn_act_bwd_finalize(partials, rows, c, count, gamma, invstd, dgamma, dbeta, 
                                         _ptr(coef), _stream()), "bn_act_bwd_finalize")
 
 
-def bn_act_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, coef) -> None:
+def bn_act_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, coef,
+                     dropout=(0.0, 0)) -> None:
     ady, ax, adx = act(dy), act(x), act(dx)
     check(lib.segmi_bn_act_bwd_apply(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx),
                                      _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                                     _ptr(prelu_alpha), _ptr(coef), _stream()),
+                                     _ptr(prelu_alpha), _ptr(coef), float(dropout[0]),
+                                     int(dropout[1]) & 0xFFFFFFFF, _stream()),
           "bn_act_bwd_apply")
 
 

@@ -83,11 +83,9 @@ class Net(torch.nn.Module):
         self.hparams = AttributeDict(num_classes=num_classes, num_channels=num_channels,
                                      spatial_dims=spatial_dims, spatial_size=spatial_size,
                                      channels=channels, strides=strides, dropout=dropout, act=act)
-        if dropout not in (0, 0.0, None):
-            raise NotImplementedError("segmantic_amd implements dropout=0.0 (the reference default)")
         self._model = UNetParams(spatial_dims=spatial_dims, in_channels=num_channels,
                                  out_channels=num_classes, channels=channels, strides=strides,
-                                 num_res_units=2, act=act)
+                                 num_res_units=2, act=act, dropout=dropout)
         self.spatial_size = list(spatial_size) if spatial_size else [96] * 3
         self.loss_function = DiceLoss(to_onehot_y=True, softmax=True)
         self.dice_metric = DiceMetric(num_classes, include_background=False)

@@ -96,7 +96,7 @@ class UNetParams(nn.Module):
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int,
                  channels: Sequence[int], strides: Sequence[int], num_res_units: int = 2,
-                 kernel_size: int = 3, act: str = "PRELU"):
+                 kernel_size: int = 3, act: str = "PRELU", dropout: float = 0.0):
         super().__init__()
         if len(channels) < 2:
             raise ValueError("the length of `channels` should be no less than 2.")
@@ -108,6 +108,9 @@ class UNetParams(nn.Module):
         if act != "PRELU" and act not in FIXED_SLOPE:
             raise NotImplementedError(f"segmantic_amd implements act in PRELU / RELU / LEAKYRELU, not {act}")
         self.act = act
+        self.dropout = float(dropout or 0.0)
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
         self.dimensions = spatial_dims
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -248,6 +251,16 @@ class _BN:
         self.shift = torch.empty(c, device=dev)
         self.coef = torch.empty((2, c), device=dev)
         self._eval: Optional[tuple] = None
+        self.index = len(eng._bns)
+        eng._bns.append(self)
+
+    def drop(self) -> tuple:
+        """(p, seed) of this layer's ADN dropout for the current training step: forward and the two
+        backward passes of a step see the same seed (the mask is recomputed, never stored)."""
+        e = self.eng
+        if e.dropout_p <= 0.0:
+            return (0.0, 0)
+        return (e.dropout_p, (e.dropout_seed * 0x9E3779B1 + e._drop_step * 8191 + self.index * 131071) & 0xFFFFFFFF)
 
     def eval_affine(self):
         ver = self.eng.weights_version
@@ -278,6 +291,10 @@ class UNetEngine:
         self.weights_version = 0
         self._packed_version = -1
         self._convs: list = []
+        self._bns: list = []
+        self.dropout_p = float(getattr(params, "dropout", 0.0) or 0.0)
+        self.dropout_seed = 0
+        self._drop_step = 0
         self._wbatch = None
         self.training = True
         self._bufs: Dict[str, torch.Tensor] = {}
@@ -551,11 +568,12 @@ class UNetEngine:
         rows = ops.bn_act_bwd_rows(x_raw)
         part = self._fstat(rows, bn.c)
         count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
-        ops.bn_act_bwd_reduce(dy, x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part)
+        ops.bn_act_bwd_reduce(dy, x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part,
+                              dropout=bn.drop())
         ops.bn_act_bwd_finalize(part, rows, bn.c, count, bn.gamma, bn.invstd, bn.g_gamma,
                                 bn.g_beta, bn.g_alpha, bn.coef)
         ops.bn_act_bwd_apply(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
-                             bn.coef)
+                             bn.coef, dropout=bn.drop())
 
     # ------------------------------------------------------------------ residual unit
     def _ru_fwd_train(self, ru, x, out):
@@ -590,10 +608,10 @@ class UNetEngine:
             saved[f"r{i}"] = r
             if last:
                 self._join_branch(br)
-                ops.bn_act_fwd(r, out, bn.scale, bn.shift, bn.alpha, residual=resid)
+                ops.bn_act_fwd(r, out, bn.scale, bn.shift, bn.alpha, residual=resid, dropout=bn.drop())
             else:
                 a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
-                ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha)
+                ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
                 cur = a
         self._saved[pre] = saved
 
@@ -698,7 +716,7 @@ class UNetEngine:
         if train:
             u = self._buf(f"{p}u", oshape)
             self._conv_train(up, cat, u, ubn)
-            ops.bn_act_fwd(u, au, ubn.scale, ubn.shift, ubn.alpha)
+            ops.bn_act_fwd(u, au, ubn.scale, ubn.shift, ubn.alpha, dropout=ubn.drop())
             self._saved[p + "up"] = {"cat": cat, "u": u, "au": au}
             self._ru_fwd_train(lvl["upru"], au, out)
         else:
@@ -785,6 +803,7 @@ class UNetEngine:
         if train:
             self._saved.clear()
             self._nbt_flat += 1        # every BatchNorm runs exactly once per training forward
+            self._drop_step += 1       # fresh dropout masks for this step (shared by its backward)
         self._level_fwd(self.levels, xin, logits, train)
         return logits if self.kpad == k else logits[..., :k]     # the K real classes (view, ld = kpad)
 

@@ -446,3 +446,70 @@ def test_fixed_slope_activations_match_oracle(act):
         g, gr = net._engine._galias[key].cpu(), rp[key].grad
         # (kinked activations: pre-activations within rounding of 0 may take the other branch)
         assert float((g - gr).abs().max()) < 1e-2 * float(gr.abs().max()) + 2e-6 * gmax, key
+
+
+class _HashDropout(torch.nn.Module):
+    """Test stand-in for the oracle's nn.Dropout: the mask the HIP kernels derive from (seed, element
+    index) (norm_act.hip drop_mult), so the whole step can be compared value for value."""
+
+    def __init__(self, p, seed):
+        super().__init__()
+        self.p, self.seed = p, seed
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        from test_ops_gpu import _drop_mask
+        n, c = x.shape[:2]
+        sp = tuple(x.shape[2:])
+        m = torch.from_numpy(_drop_mask(x.numel(), self.p, self.seed)).reshape((n,) + sp + (c,))
+        return x * m.permute(0, 4, 1, 2, 3)
+
+
+def test_dropout_training_step_matches_oracle_with_the_same_masks():
+    """`dropout` of the config schema (monai_unet.py:83-92 -> UNet(dropout=...)): ADN order norm ->
+    dropout -> act; eval ignores it; a training step reproduces the oracle given the same masks."""
+    pd = 0.2
+    ref = deterministic_fill_(RefUNet(3, 1, 16, (16, 32, 64), (2, 2), dropout=pd), 0)
+    net = Net(num_classes=16, num_channels=1, channels=(16, 32, 64), strides=(2, 2), dropout=pd)
+    net0 = Net(num_classes=16, num_channels=1, channels=(16, 32, 64), strides=(2, 2))
+    sd = {"_model." + k: v.clone() for k, v in ref.state_dict().items()}
+    net.load_state_dict(sd); net0.load_state_dict(sd)
+    net.to(DEV); net0.to(DEV)
+    net.mixed_precision = net0.mixed_precision = False
+    img, lab = synthetic_batch(2, 32, 16, seed=21)
+    net.eval(); net0.eval()
+    with torch.no_grad():
+        assert torch.equal(net(img.to(DEV)), net0(img.to(DEV)))        # eval: dropout is the identity
+    net.train(); ref.train()
+    eng = net._engine_for()
+    eng.dropout_seed = 1234
+    # masks of the first training forward (_drop_step 0 -> 1)
+    eng._drop_step = 0
+    seeds = {}
+    eng._drop_step += 1
+    for bn in eng._bns:
+        seeds[bn.prefix] = bn.drop()[1]
+    eng._drop_step -= 1
+    assert len(set(seeds.values())) == len(seeds)
+    for prefix, seed in seeds.items():
+        mod = ref.model.get_submodule(prefix)       # engine prefixes are relative to `model.`
+        mod.D = _HashDropout(pd, seed)
+    y_ref = ref(img)
+    loss_ref = ref_dice_loss(y_ref, lab)
+    loss_ref.backward()
+    res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+    torch.cuda.synchronize()
+    y = eng._bufs["logits.t"][..., :16].float().cpu().permute(0, 4, 1, 2, 3).clone()
+    assert float((y - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 2e-4
+    assert abs(float(res["loss"].detach().cpu()) - float(loss_ref.detach())) < 1e-4 * float(loss_ref.detach())
+    rp = dict(ref.named_parameters())
+    gmax = max(float(t.grad.abs().max()) for t in rp.values())
+    for key, gr in ((k, t.grad) for k, t in rp.items() if k.endswith("conv.weight") or ".N.weight" in k):
+        g = eng._galias[key].cpu()
+        assert float((g - gr).abs().max()) < 5e-3 * float(gr.abs().max()) + 2e-6 * gmax, key
+    # the next step draws different masks
+    net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+    torch.cuda.synchronize()
+    y2 = eng._bufs["logits.t"][..., :16].float().cpu().permute(0, 4, 1, 2, 3)
+    assert float((y2 - y).abs().max()) > 1e-2 * float(y.abs().max())

@@ -404,6 +404,77 @@ def test_bn_prelu_fwd_bwd(dtype, c):
     assert relerr(from_ndhwc(dxd), xq.grad) < (1e-4 if dtype == torch.float32 else 1.5e-2)
 
 
+def _drop_mask(numel, p, seed):
+    """numpy restatement of norm_act.hip drop_mult (keep -> 1/(1-p), drop -> 0) over element indices."""
+    e = np.arange(numel, dtype=np.uint64)
+    h = ((e & 0xFFFFFFFF) * 0x9E3779B1) & 0xFFFFFFFF
+    h ^= np.uint64(seed)
+    h ^= ((e >> np.uint64(32)) * 0x85EBCA77) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16); h = (h * 0x7FEB352D) & 0xFFFFFFFF
+    h ^= h >> np.uint64(15); h = (h * 0x846CA68B) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16)
+    keep = (h >> np.uint64(8)) >= np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    return keep.astype(np.float32) / (1.0 - p)
+
+
+@pytest.mark.parametrize("c", [3, 16, 64])
+def test_bn_dropout_prelu_fwd_bwd(c):
+    """ADN ordering "NDA" (MONAI blocks/adn.py as used by monai_unet.py:83-92): norm -> dropout -> act.
+    The mask is a counter hash of the logical element index, recomputed in backward."""
+    dtype = torch.float32
+    n, sp = 2, (6, 10, 14)
+    pdrop, seed = 0.3, 0xC0FFEE
+    x = rnd((n, c) + sp, 151, 2.0)
+    gamma = 1 + 0.2 * rnd((c,), 152)
+    beta = 0.1 * rnd((c,), 153)
+    alpha = torch.tensor([0.25])
+    dy = rnd((n, c) + sp, 155)
+    count = n * sp[0] * sp[1] * sp[2]
+    mask_ndhwc = torch.from_numpy(_drop_mask(count * c, pdrop, seed)).reshape((n,) + sp + (c,))
+    mask = mask_ndhwc.permute(0, 4, 1, 2, 3)
+    assert abs(float((mask > 0).float().mean()) - (1 - pdrop)) < 0.02
+    xq = x.clone().requires_grad_(True)
+    g0, b0, a0 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    z = F.batch_norm(xq, None, None, g0, b0, training=True, eps=1e-5)
+    y = F.prelu(z * mask, a0)
+    y.backward(dy)
+
+    xd = to_ndhwc(x, dtype)
+    rows = ops.bn_stats_rows(xd)
+    part = torch.empty((rows, 2, c), device=DEV)
+    ops.bn_stats(xd, part)
+    mean, invstd, scale, shift = (torch.empty(c, device=DEV) for _ in range(4))
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    gd, bd, ad = gamma.to(DEV), beta.to(DEV), alpha.to(DEV)
+    ops.bn_finalize(part, rows, c, count, gd, bd, rmd, rvd, 0.1, 1e-5, mean, invstd, scale, shift)
+    yd = torch.empty_like(xd)
+    ops.bn_act_fwd(xd, yd, scale, shift, ad, None, dropout=(pdrop, seed))
+    torch.cuda.synchronize()
+    got = from_ndhwc(yd)
+    assert torch.equal(got == 0, (mask == 0) | (y.detach() == 0))     # the very same voxels are dropped
+    assert relerr(got, y.detach()) < 1e-5
+    dyd = to_ndhwc(dy, dtype)
+    rrows = ops.bn_act_bwd_rows(xd)
+    rp = torch.empty((rrows, 3, c), device=DEV)
+    ops.bn_act_bwd_reduce(dyd, xd, mean, invstd, gd, bd, ad, rp, dropout=(pdrop, seed))
+    dg, dbt, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty((2, c), device=DEV)
+    da = torch.empty(1, device=DEV)
+    ops.bn_act_bwd_finalize(rp, rrows, c, count, gd, invstd, dg, dbt, da, coef)
+    dxd = torch.empty_like(xd)
+    ops.bn_act_bwd_apply(dyd, xd, dxd, mean, invstd, gd, bd, ad, coef, dropout=(pdrop, seed))
+    torch.cuda.synchronize()
+    assert relerr(dg.cpu(), g0.grad) < 1e-4
+    assert relerr(dbt.cpu(), b0.grad) < 1e-4
+    assert relerr(da.cpu(), a0.grad) < 1e-4
+    assert relerr(from_ndhwc(dxd), xq.grad) < 1e-4
+    # p = 0 is the identity (no mask evaluated)
+    y0 = torch.empty_like(xd)
+    ops.bn_act_fwd(xd, y0, scale, shift, ad, None, dropout=(0.0, seed))
+    y1 = torch.empty_like(xd)
+    ops.bn_act_fwd(xd, y1, scale, shift, ad, None)
+    assert torch.equal(y0, y1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k", [2, 3, 16, 32])
 def test_softmax_dice(dtype, k):
