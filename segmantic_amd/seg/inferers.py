@@ -18,6 +18,7 @@ read-modify-written per window group, ``segmi_sw_scatter_add``).
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -72,6 +73,21 @@ class SlidingWindowResult:
 
     def __init__(self, logits, labels, count):
         self.logits, self.labels, self.count = logits, labels, count
+
+
+_LANES: dict = {}
+
+
+def _lane_streams(device):
+    """Two streams for alternating window groups (SEGMI_SW_LANES=1 keeps everything on the current
+    stream, e.g. for per-kernel profiling)."""
+    n = int(os.environ.get("SEGMI_SW_LANES", "2"))
+    if n < 2 or os.environ.get("SEGMI_SERIAL"):
+        return None
+    key = (torch.device(device).index, n)
+    if key not in _LANES:
+        _LANES[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _LANES[key]
 
 
 def _cache_budget_bytes(device) -> int:
@@ -166,17 +182,39 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     want_logits = return_logits or not return_labels or partial
     nvox_roi = roi[0] * roi[1] * roi[2]
     outs, labs, cnts = [], [], []
+    lanes = _lane_streams(dev) if into is not None else None
     for b in range(B):
         acc = cnt = cache = None
         K = None
         deferred = False
-        for g0 in range(lo, hi, sw_batch_size):
+        main = torch.cuda.current_stream(dev)
+        forked = False
+        for gi, g0 in enumerate(range(lo, hi, sw_batch_size)):
             grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
+            slot = g0 - lo
+            if cache is not None and into is not None and lanes is not None:
+                # window groups are independent once their predictions go to the cache: alternate
+                # them over two streams (each with its own activation lane of the engine) so the
+                # small deep layers of one group overlap the wide layers of the other
+                if not forked:
+                    for st in lanes:
+                        st.wait_stream(main)
+                    forked = True
+                lane = gi % len(lanes)
+                with torch.cuda.stream(lanes[lane]):
+                    wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
+                                       device=dev)
+                    ops.sw_gather(img, b, grp, wbuf)
+                    ok = into(wbuf.permute(0, 4, 1, 2, 3), cache[slot:slot + len(grp)], lane)
+                if ok:
+                    continue
+                if gi > 1:
+                    raise RuntimeError("predictor stopped accepting forward_into mid-volume")
+                into = None          # e.g. a class count the cache layout cannot take directly
             wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
                                device=dev)
             ops.sw_gather(img, b, grp, wbuf)
             wview = wbuf.permute(0, 4, 1, 2, 3)
-            slot = g0 - lo
             if cache is not None and into is not None and into(wview, cache[slot:slot + len(grp)]):
                 continue                                   # predicted straight into the cache
             pn = as_ndhwc(predictor(wview))
@@ -196,6 +234,9 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                 cache[slot:slot + len(grp)].copy_(pn)
             else:
                 ops.sw_scatter_add(pn, grp, acc, cnt, imp)
+        if forked:
+            for st in lanes:
+                main.wait_stream(st)
         lab = None
         if not partial and return_labels:
             lab = torch.empty((out_d, orig[1], orig[2]),

@@ -163,7 +163,7 @@ class Net(torch.nn.Module):
         out = logits_ndhwc.permute(0, 4, 1, 2, 3)
         return out.squeeze(2) if x.dim() == 4 else out
 
-    def forward_into(self, x: torch.Tensor, out_ndhwc: torch.Tensor) -> bool:
+    def forward_into(self, x: torch.Tensor, out_ndhwc: torch.Tensor, lane: int = 0) -> bool:
         """Inference forward straight into a caller-owned NDHWC [B, D, H, W, K] buffer of the
         compute dtype (the sliding-window prediction cache).  Returns False when the module is in
         training mode or the buffer does not fit, so the caller falls back to ``forward``."""
@@ -172,7 +172,7 @@ class Net(torch.nn.Module):
                 or eng.kpad != eng.net.out_channels):
             return False
         with torch.cuda.device(eng.device):
-            eng.forward(x, train=False, out=out_ndhwc)
+            eng.forward(x, train=False, out=out_ndhwc, lane=lane)
         return True
 
     # ------------------------------------------------------------------ optimisers

@@ -299,6 +299,7 @@ class UNetEngine:
         self.training = True
         self._bufs: Dict[str, torch.Tensor] = {}
         self._scratch: Dict[str, torch.Tensor] = {}
+        self._lane = 0
         self._saved: Dict[str, torch.Tensor] = {}
         self.timings: Dict[str, list] = {}
         self.fixed_slope = torch.full((1,), FIXED_SLOPE.get(params.act, 0.0), dtype=torch.float32,
@@ -480,6 +481,8 @@ class UNetEngine:
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, shape, dtype=None) -> torch.Tensor:
         dtype = dtype or self.dtype
+        if self._lane:                      # a second in-flight forward owns its own activations
+            name = f"lane{self._lane}:{name}"
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
             t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
@@ -487,6 +490,8 @@ class UNetEngine:
         return t
 
     def _scratch_buf(self, name, nbytes) -> torch.Tensor:
+        if self._lane:
+            name = f"lane{self._lane}:{name}"
         t = self._scratch.get(name)
         if t is None or t.numel() < nbytes:
             t = torch.empty((int(nbytes * 1.25) // 256 + 2) * 256, dtype=torch.uint8,
@@ -779,13 +784,24 @@ class UNetEngine:
         return xin
 
     def forward(self, x: torch.Tensor, train: Optional[bool] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, lane: int = 0) -> torch.Tensor:
         """[N,C,D,H,W] f32 -> logits NDHWC tensor [N,D,H,W,K] (compute dtype).
 
         ``out`` (eval mode): caller-owned dense NDHWC destination of the compute dtype, e.g. a
         slot range of the sliding-window prediction cache; otherwise an engine buffer that the
-        next call overwrites."""
+        next call overwrites.  ``lane`` (eval mode): activation-buffer set to use, so that forwards
+        issued on different streams can be in flight together (weights and folded packs are shared:
+        the caller orders the first forward after a weight change before any concurrent one)."""
         train = self.training if train is None else train
+        if lane and train:
+            raise ValueError("lanes are an inference-only feature")
+        self._lane = int(lane)
+        try:
+            return self._forward(x, train, out)
+        finally:
+            self._lane = 0
+
+    def _forward(self, x, train, out):
         xin = self._prep_input(x)
         n, d, h, w, _ = xin.shape
         k = self.net.out_channels
