@@ -86,6 +86,19 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
                      float* stats_partials, int ksize, int stride, void* stream);
+/* The first ResidualUnit of the network convolves its (<= 4 channel) input twice with the same
+ * geometry: subunit 0 (k3, stride s) and the residual convolution (k3, stride s).  One launch
+ * stages the input once and produces both:  out_a = prelu_a(conv_a(in) + bias_a) with optional
+ * statistics of the pre-activation values (rows as segmi_conv3d_stats_rows(in, out_a)),
+ * out_b = conv_b(in) + bias_b.  w_a / w_b are torch-layout f32 [cout][cin][27].
+ * segmi_conv3d_pair_ok() says whether the layer qualifies (1) or needs two segmi_conv3d_fwd (0).
+ * Replaces the two torch.nn.Conv3d of monai ResidualUnit, monai_unet.py:114-124. */
+int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
+                         const segmi_act* out_b);
+int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
+                          const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
+                          const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,
+                          void* stream);
 
 /* ConvTranspose3d k3 s2 p1 (output extent 2*in or 2*in-1 per dim, taken from `out`),
  * same fused epilogue.  Also the dgrad of a stride-2 Conv3d.

@@ -18,7 +18,8 @@ int stats_reserve_rows();
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
                    const float* bias, const float* alpha, const segmi_act* res, float* stats,
-                   int stride, hipStream_t st);
+                   int stride, hipStream_t st, const segmi_act* out2 = nullptr,
+                   const float* w2 = nullptr, const float* bias2 = nullptr);
 int conv_small_fwd_rows(const segmi_act* out);
 
 struct DirectParams {
@@ -148,6 +149,31 @@ int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out
   }
   if (small_fwd_eligible(dtype, in, out, ksize)) return conv_small_fwd_rows(out) + stats_reserve_rows();
   return bn_stats_rows_for(out) + stats_reserve_rows();
+}
+
+int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
+                         const segmi_act* out_b) {
+  if (!act_ok(in) || !act_ok(out_a) || !act_ok(out_b)) return 0;
+  if (dtype != SEGMI_F32 && dtype != SEGMI_BF16) return 0;
+  return !mfma_ok(in->c, out_a->c) && small_fwd_eligible(dtype, in, out_a, 3) &&
+         small_fwd_eligible(dtype, in, out_b, 3) && out_a->c == out_b->c && out_a->n == out_b->n &&
+         out_a->d == out_b->d && out_a->h == out_b->h && out_a->w == out_b->w;
+}
+
+int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
+                          const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
+                          const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,
+                          void* stream) {
+  SEGMI_CHECK_ARG(segmi_conv3d_pair_ok(dtype, in, out_a, out_b),
+                  "conv3d_fwd_pair: not a small-Cin k3 pair (ask segmi_conv3d_pair_ok first)");
+  SEGMI_CHECK_ARG(w_a && w_b && (stride == 1 || stride == 2), "conv3d_fwd_pair: bad arguments");
+  SEGMI_CHECK_ARG(in->n == out_a->n && out_a->d == out_extent(in->d, 3, stride) &&
+                      out_a->h == out_extent(in->h, 3, stride) && out_a->w == out_extent(in->w, 3, stride),
+                  "conv3d_fwd_pair: output extent does not match the input");
+  SEGMI_CHECK_ARG(!(stats_partials_a && prelu_alpha_a),
+                  "conv3d_fwd_pair: fused statistics are taken before PReLU");
+  return conv_small_fwd(dtype, in, out_a, w_a, bias_a, prelu_alpha_a, nullptr, stats_partials_a,
+                        stride, (hipStream_t)stream, out_b, w_b, bias_b);
 }
 
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,

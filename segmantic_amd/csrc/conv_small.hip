@@ -20,6 +20,13 @@ struct SmallConvParams {
   float* stats;        // per-workgroup partial sums [grid.x][2][Cout] (nullable)
   int N, Di, Hi, Wi, Do, Ho, Wo, Cout, ldi, ldo, ldr;
   int tz, ty, tx;
+  // PAIR: a second convolution of the same input and geometry (the residual convolution of the
+  // unit): its own weights / bias / destination, no activation, no statistics
+  void* out2;
+  const float* w2;
+  const float* bias2;
+  int ldo2;
+  int vec;   // Cin == 1 rows can be staged with 4-element loads (dense, 4-aligned W and base)
 };
 
 // MFMA forward for tiny Cin:  D[co][vox] += W[co][k] * X[k][vox] with k = ci*27 + tap (the torch
@@ -29,14 +36,14 @@ struct SmallConvParams {
 // whole convolution of 16 voxels x 16 channels is ONE v_mfma_f32_16x16x32_bf16 for Cin = 1.
 // Tile = 4 x 8 x 16 output voxels (32 voxel tiles, 8 per wave); epilogue as conv_fwd_impl.h.
 // compile-time halo offset of k = ci*27 + tap (0 for the zero padding beyond 27*CIN)
-template <int CIN, int HD, int HH, int HW>
+template <int CIN, int HD, int HH, int XW>
 __host__ __device__ constexpr int small_koff(int k) {
   if (k >= 27 * CIN) return 0;
   const int ci = k / 27, tap = k % 27;
-  return ((ci * HD + tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+  return ((ci * HD + tap / 9) * HH + (tap / 3) % 3) * XW + tap % 3;
 }
 
-template <typename T, int S, int CIN>
+template <typename T, int S, int CIN, bool PAIR>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int KG = Elem<T>::KG;                      // k-values per lane per MFMA operand
@@ -44,11 +51,12 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   constexpr int NK = (27 * CIN + KSTEP - 1) / KSTEP;   // k-steps
   constexpr int TD = 4, TH = 8, TW = 16;
   constexpr int HD = (TD - 1) * S + 3, HH = (TH - 1) * S + 3, HW = (TW - 1) * S + 3;
+  constexpr int XW = (HW + 3 + 3) / 4 * 4;             // LDS row: 3 lead-in elements + HW, 4-padded
   constexpr int NROWS = CIN * HD * HH;                 // halo rows of HW elements
   constexpr int RPI = 256 / HW < HH ? 256 / HW : HH;   // rows staged per iteration (<= one row wrap)
   constexpr int NIT = (NROWS + RPI - 1) / RPI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* xs = reinterpret_cast<T*>(smem);                  // [CIN][HD][HH][HW]
+  T* xs = reinterpret_cast<T*>(smem);                  // [CIN][HD][HH][XW], halo x = 0 at column 3
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -69,7 +77,34 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   const int hx = tid % HW;
   const bool xlive = tid < RPI * HW && (unsigned)(ix0 + hx) < (unsigned)p.Wi;
   T stg[NIT];
-  {
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) stg[k] = (T)0;
+  // single-channel dense rows: the halo row [ix0 - 3, ix0 - 3 + XW) starts on a multiple of 4
+  // elements (ix0 = TW*S*tx - 1, TW*S % 4 == 0), so it is XW/4 aligned 4-element loads -- 6 loads per
+  // thread for the stride-2 first layer instead of 22 two-byte ones
+  typedef typename std::conditional<ES == 2, u32x2, f32x4>::type Vec4;
+  constexpr int GPR = XW / 4, NGRP = NROWS * GPR, NITV = (NGRP + 255) / 256;
+  Vec4 vstg[CIN == 1 ? NITV : 1];
+  const bool vec = CIN == 1 && p.vec;
+  if (vec) {
+    const int sy = p.Wi, sz = p.Hi * sy;
+#pragma unroll
+    for (int k = 0; k < NITV; ++k) {
+      const int gi = tid + 256 * k;
+      const int row = gi / GPR, gq = gi % GPR;
+      const int hy = row % HH, hz = row / HH;
+      const int x0 = ix0 - 3 + 4 * gq;
+      vstg[k] = Vec4{};
+      if (gi < NGRP && (unsigned)(iz0 + hz) < (unsigned)p.Di && (unsigned)(iy0 + hy) < (unsigned)p.Hi &&
+          (unsigned)x0 < (unsigned)p.Wi)
+        vstg[k] = *reinterpret_cast<const Vec4*>(tile + hz * sz + hy * sy + (4 * gq - 3));
+    }
+#pragma unroll
+    for (int k = 0; k < NITV; ++k) {
+      const int gi = tid + 256 * k;
+      if (gi < NGRP) *reinterpret_cast<Vec4*>(xs + 4 * gi) = vstg[k];
+    }
+  } else {
     static_assert(RPI <= HH, "at most one row wrap per iteration");
     int row = tid / HW;                                // row = (ci * HD + hz) * HH + hy
     int hy = row % HH, hz = (row / HH) % HD;
@@ -91,18 +126,18 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
       }
     }
   }
-  if (tid < RPI * HW) {
+  if (!vec && tid < RPI * HW) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int row = tid / HW + RPI * k;
-      if (row < NROWS) xs[row * HW + hx] = stg[k];
+      if (row < NROWS) xs[row * XW + 3 + hx] = stg[k];
     }
   }
   // ---- weight operand: lane (co = r, g) holds k = KSTEP*s + KG*g + j; the halo offset of that k
   // is a compile-time constant per lane group, plus the lane's voxel (x = r, plane z = wave)
-  frag_t wf[NK];
+  frag_t wf[NK], wf2[PAIR ? NK : 1];
   int lk[NK][KG];
-  const int lane_vox = (wave * S * HH) * HW + r * S;
+  const int lane_vox = (wave * S * HH) * XW + 3 + r * S;
 #pragma unroll
   for (int s = 0; s < NK; ++s) {
     float wv[KG];
@@ -110,10 +145,10 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
     for (int j = 0; j < KG; ++j) {
       const int k = KSTEP * s + KG * g + j;
       wv[j] = k < 27 * CIN ? p.w[(co0 + r) * 27 * CIN + k] : 0.f;
-      const int o0 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 0 + j);
-      const int o1 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 1 + j);
-      const int o2 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 2 + j);
-      const int o3 = small_koff<CIN, HD, HH, HW>(KSTEP * s + KG * 3 + j);
+      const int o0 = small_koff<CIN, HD, HH, XW>(KSTEP * s + KG * 0 + j);
+      const int o1 = small_koff<CIN, HD, HH, XW>(KSTEP * s + KG * 1 + j);
+      const int o2 = small_koff<CIN, HD, HH, XW>(KSTEP * s + KG * 2 + j);
+      const int o3 = small_koff<CIN, HD, HH, XW>(KSTEP * s + KG * 3 + j);
       lk[s][j] = lane_vox + (g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3);
     }
     if constexpr (ES == 2) {
@@ -123,7 +158,24 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
       wf[s] = frag_t{__float_as_uint(wv[0]), __float_as_uint(wv[1]), __float_as_uint(wv[2]),
                      __float_as_uint(wv[3])};
     }
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int j = 0; j < KG; ++j) {
+        const int k = KSTEP * s + KG * g + j;
+        wv[j] = k < 27 * CIN ? p.w2[(co0 + r) * 27 * CIN + k] : 0.f;
+      }
+      if constexpr (ES == 2) {
+        wf2[s] = frag_t{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]),
+                        pack_bf16x2(wv[6], wv[7])};
+      } else {
+        wf2[s] = frag_t{__float_as_uint(wv[0]), __float_as_uint(wv[1]), __float_as_uint(wv[2]),
+                        __float_as_uint(wv[3])};
+      }
+    }
   }
+  f32x4 bias4b = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (PAIR && p.bias2) bias4b = *reinterpret_cast<const f32x4*>(p.bias2 + co0 + 4 * g);
+  touch_v(bias4b);
   f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co0 + 4 * g);
   const bool has_alpha = p.alpha != nullptr;
@@ -133,24 +185,26 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   __syncthreads();
 
   // ---- wave w computes plane z = w of the tile; voxel tile i = row y = i (x = r)
-  f32x4 acc[8];
+  f32x4 acc[8], acc2[PAIR ? 8 : 1];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PAIR) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
       frag_t a;
       if constexpr (ES == 2) {
         unsigned short e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = xs[lk[s][j] + i * S * HW];
+        for (int j = 0; j < 8; ++j) e[j] = xs[lk[s][j] + i * S * XW];
         a = frag_t{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
                    (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(xs[lk[s][j] + i * S * HW]);
+        for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(xs[lk[s][j] + i * S * XW]);
       }
       acc[i] = mma16<T>(wf[s], a, acc[i]);
+      if constexpr (PAIR) acc2[i] = mma16<T>(wf2[s], a, acc2[i]);
     }
   }
 
@@ -173,6 +227,10 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   }
 #pragma unroll
   for (int k = 0; k < NIT; ++k) touch_v(stg[k]);
+  if constexpr (CIN == 1) {
+#pragma unroll
+    for (int k = 0; k < NITV; ++k) touch_v(vstg[k]);
+  }
   f32x4 ssum = f32x4{0.f, 0.f, 0.f, 0.f}, ssq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -186,6 +244,14 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
       if (rrow) v += resv[i];
       store4<T>(orow + i * ostep + lo_out, v);
     }
+  }
+  if constexpr (PAIR) {
+    T* orow2 = (T*)p.out2 + ((((int64_t)n * p.Do + oz) * p.Ho + oy0) * p.Wo) * p.ldo2;
+    const unsigned lo_out2 = (unsigned)(ox * p.ldo2 + co0 + 4 * g);
+    const int ostep2 = p.Wo * p.ldo2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (zx_ok && oy0 + i < p.Ho) store4<T>(orow2 + i * ostep2 + lo_out2, acc2[i] + bias4b);
   }
   if (p.stats) {
     __syncthreads();
@@ -396,21 +462,25 @@ int conv_small_fwd_rows(const segmi_act* out) {
   return out->n * cdiv(out->d, 4) * cdiv(out->h, 8) * cdiv(out->w, 16);
 }
 
-template <typename T, int S, int CIN>
-static int launch_small_fwd(SmallConvParams p, hipStream_t st) {
-  constexpr int HD = 3 * S + 3, HH = 7 * S + 3, HW = 15 * S + 3;
-  constexpr int stage = CIN * HD * HH * HW * (int)sizeof(T);
+template <typename T, int S, int CIN, bool PAIR>
+static int launch_small_fwd_k(SmallConvParams p, hipStream_t st) {
+  constexpr int HD = 3 * S + 3, HH = 7 * S + 3, HW = 15 * S + 3, XW = (HW + 6) / 4 * 4;
+  constexpr int stage = CIN * HD * HH * XW * (int)sizeof(T);
   constexpr int lds = stage > 4 * 2 * 16 * 4 ? stage : 4 * 2 * 16 * 4;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_small_fwd_kernel<T, S, CIN>,
+    (void)hipFuncSetAttribute((const void*)conv_small_fwd_kernel<T, S, CIN, PAIR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.Cout / 16));
-  hipLaunchKernelGGL((conv_small_fwd_kernel<T, S, CIN>), grid, 256, lds, st, p);
+  hipLaunchKernelGGL((conv_small_fwd_kernel<T, S, CIN, PAIR>), grid, 256, lds, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(small-cin)");
   return SEGMI_OK;
+}
+template <typename T, int S, int CIN>
+static int launch_small_fwd(const SmallConvParams& p, hipStream_t st) {
+  return p.out2 ? launch_small_fwd_k<T, S, CIN, true>(p, st) : launch_small_fwd_k<T, S, CIN, false>(p, st);
 }
 template <typename T, int S>
 static int launch_small_fwd_cin(const SmallConvParams& p, int cin, hipStream_t st) {
@@ -424,8 +494,12 @@ static int launch_small_fwd_cin(const SmallConvParams& p, int cin, hipStream_t s
 
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
                    const float* bias, const float* alpha, const segmi_act* res, float* stats,
-                   int stride, hipStream_t st) {
+                   int stride, hipStream_t st, const segmi_act* out2, const float* w2,
+                   const float* bias2) {
   SmallConvParams p{};
+  if (out2) { p.out2 = out2->data; p.w2 = w2; p.bias2 = bias2; p.ldo2 = out2->ld; }
+  p.vec = in->c == 1 && in->ld == 1 && in->w % 4 == 0 &&
+          ((uintptr_t)in->data % (4 * (dtype == SEGMI_F32 ? 4 : 2))) == 0;
   p.in = in->data; p.out = out->data; p.w = w; p.bias = bias; p.alpha = alpha;
   p.res = res ? res->data : nullptr; p.ldr = res ? res->ld : 0; p.stats = stats;
   p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h; p.Wo = out->w;

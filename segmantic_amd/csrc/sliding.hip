@@ -219,19 +219,21 @@ __global__ __launch_bounds__(256) void sw_blend_kernel(
     const T* __restrict__ cache, BlendSched sc, int lo, int hi, const float* __restrict__ imp,
     float* __restrict__ out, float* __restrict__ cnt_out, L* __restrict__ labels, int D, int H,
     int W, int K, int ldo, int rd, int rh, int rw, int ldp, int normalize) {
+  // A workgroup takes 256-lane segments of one output row (z, y): z, y and with them the covering
+  // windows of those two dimensions are wave-uniform (scalar loops), only x is per lane, and no
+  // lane does a 64-bit division (the flat-index form spent more time dividing than loading).
   const int tpv = K / G;
-  const int64_t nvox = (int64_t)D * H * W;
-  const int64_t total = nvox * tpv;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t e0 = blockIdx.x * 256ll; e0 < total; e0 += stride) {
-    const int64_t e = e0 + threadIdx.x;
-    const bool live = e < total;
-    const int64_t v = live ? e / tpv : 0;
-    const int k = (int)(e % tpv) * G;
-    int64_t t = v;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int z = (int)(t / H);
+  const int lanes_row = W * tpv;
+  const int segs = (lanes_row + 255) / 256;
+  const int nseg = D * H * segs;
+  for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const int seg = s % segs, row = s / segs;
+    const int y = row % H, z = row / H;
+    const int e = seg * 256 + (int)threadIdx.x;
+    const bool live = e < lanes_row;
+    const int x = live ? e / tpv : 0;
+    const int k = live ? (e % tpv) * G : 0;
+    const int64_t v = (int64_t)row * W + x;
     float a[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) a[j] = 0.f;
@@ -535,9 +537,9 @@ int segmi_sw_blend(int dtype, const void* cache, int k, int ldp, const int32_t* 
   SEGMI_CHECK_ARG(vec || !labels || k <= 64,
                   "sw_blend: the scalar path (K %% %d != 0) labels at most 64 classes", gfull);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t nvox = (int64_t)d * h * w;
-  const int64_t lanes = nvox * (vec ? k / gfull : k);
-  const int grid = grid_for(lanes);
+  const int64_t row_segs = (int64_t)d * h * (((int64_t)w * (vec ? k / gfull : k) + 255) / 256);
+  SEGMI_CHECK_ARG(row_segs < (1ll << 31) && (int64_t)w * k < (1ll << 30), "sw_blend: volume too large");
+  const int grid = (int)(row_segs < 16384 ? row_segs : 16384);
 #define BLEND(TT, LL, GG)                                                                         \
   hipLaunchKernelGGL((sw_blend_kernel<TT, LL, GG>), grid, 256, 0, st, (const TT*)cache, sc, win_lo, \
                      win_hi, importance, out_logits, out_count, (LL*)labels, d, h, w, k, ldo, rd, \

@@ -138,6 +138,20 @@ def conv3d_fwd(x, y, packed, w_src, w_kind, bias, ksize, stride, prelu_alpha=Non
                                _ptr(stats), ksize, stride, _stream()), "conv3d_fwd")
 
 
+def conv3d_pair_ok(x, y_a, y_b) -> bool:
+    ax, aa, ab = act(x), act(y_a), act(y_b)
+    return bool(lib.segmi_conv3d_pair_ok(dtype_code(x), C.byref(ax), C.byref(aa), C.byref(ab)))
+
+
+def conv3d_fwd_pair(x, y_a, w_a, bias_a, y_b, w_b, bias_b, stride, prelu_alpha_a=None,
+                    stats_a=None) -> None:
+    """Subunit-0 and residual convolution of a small-Cin ResidualUnit in one launch."""
+    ax, aa, ab = act(x), act(y_a), act(y_b)
+    check(lib.segmi_conv3d_fwd_pair(dtype_code(x), C.byref(ax), C.byref(aa), _ptr(w_a), _ptr(bias_a),
+                                    _ptr(prelu_alpha_a), _ptr(stats_a), C.byref(ab), _ptr(w_b),
+                                    _ptr(bias_b), stride, _stream()), "conv3d_fwd_pair")
+
+
 def convT3d_stats_rows(x, y) -> int:
     ax, ay = act(x), act(y)
     return int(lib.segmi_convT3d_stats_rows(dtype_code(x), C.byref(ax), C.byref(ay)))

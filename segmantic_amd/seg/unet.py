@@ -509,6 +509,17 @@ class UNetEngine:
         return (n, f(d), f(h), f(w))
 
     # ------------------------------------------------------------------ primitive steps
+    def _pair_ok(self, ru, x, out, dst_name, oshape) -> bool:
+        """subunit 0 + residual convolution of a small-Cin unit can share one launch
+        (segmi_conv3d_fwd_pair): two or more subunits, both k3 with the same stride"""
+        units, rc = ru["units"], ru["res"]
+        if len(units) < 2 or units[0][1] is None or rc is None:
+            return False
+        c0 = units[0][0]
+        if c0.mfma or rc.mfma or c0.k != 3 or rc.k != 3 or c0.stride != rc.stride or c0.cout != rc.cout:
+            return False
+        return ops.conv3d_pair_ok(x, self._buf(dst_name, oshape + (c0.cout,)), out)
+
     def _conv_train(self, conv: _Conv, x, y, bn: Optional[_BN]):
         """raw conv (+bias) with fused statistics, then finalize into bn.*"""
         stats = None
@@ -590,16 +601,35 @@ class UNetEngine:
         # residual branch straight into `out` (read back as the epilogue residual of the last
         # unit); it is independent of the conv-unit chain, so it runs on a side stream
         br = None
+        paired = False
         if ru["res"] is not None:
             rc = ru["res"]
-            br = self._fork_branch()
-            with torch.cuda.stream(br) if br is not None else _NullCtx():
-                ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
+            paired = self._pair_ok(ru, x, out, f"{pre}.r0", (n, d, h, w))
+            if not paired:
+                br = self._fork_branch()
+                with torch.cuda.stream(br) if br is not None else _NullCtx():
+                    ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
             resid = out
         else:
             resid = x
         for i, (conv, bn) in enumerate(ru["units"]):
             last = i == nun - 1
+            if i == 0 and paired:
+                # first layer: subunit 0 and the residual convolution share one staging of x
+                r = self._buf(f"{pre}.r{i}", (n, d, h, w, conv.cout))
+                rows = ops.conv3d_stats_rows(x, r, conv.k, conv.stride)
+                stats = self._fstat(rows, conv.cout)
+                rc = ru["res"]
+                self._timed(conv.prefix + ":fwd", ops.conv3d_fwd_pair, x, r, conv.w, conv.b, out,
+                            rc.w, rc.b, conv.stride, stats_a=stats)
+                ops.bn_finalize(stats, rows, conv.cout, n * d * h * w, bn.gamma, bn.beta, bn.rm,
+                                bn.rv, self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
+                saved[f"in{i}"] = cur
+                saved[f"r{i}"] = r
+                a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
+                ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
+                cur = a
+                continue
             if bn is None:
                 # conv-only last unit (top of the net): out = conv(cur) + residual
                 self._join_branch(br)
@@ -674,11 +704,14 @@ class UNetEngine:
         pre = ru["prefix"]
         n, d, h, w = self._down_shape(x.shape, ru["stride"])
         br = None
+        paired = False
         if ru["res"] is not None:
             rc = ru["res"]
-            br = self._fork_branch()
-            with torch.cuda.stream(br) if br is not None else _NullCtx():
-                ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
+            paired = self._pair_ok(ru, x, out, f"{pre}.ea0", (n, d, h, w))
+            if not paired:
+                br = self._fork_branch()
+                with torch.cuda.stream(br) if br is not None else _NullCtx():
+                    ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
             resid = out
         else:
             resid = x
@@ -686,6 +719,15 @@ class UNetEngine:
         nun = len(ru["units"])
         for i, (conv, bn) in enumerate(ru["units"]):
             last = i == nun - 1
+            if i == 0 and paired:
+                sc, sh = bn.eval_affine()
+                _, wsrc, bias = conv.folded(sc, sh)
+                dst = self._buf(f"{pre}.ea{i}", (n, d, h, w, conv.cout))
+                rc = ru["res"]
+                ops.conv3d_fwd_pair(x, dst, wsrc, bias, out, rc.w, rc.b, conv.stride,
+                                    prelu_alpha_a=bn.alpha)
+                cur = dst
+                continue
             if bn is None:
                 self._join_branch(br)
                 ops.conv3d_fwd(cur, out, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,

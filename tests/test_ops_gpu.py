@@ -98,6 +98,42 @@ def test_conv3d_fwd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,stride,sp", [(1, 16, 2, (20, 34, 70)), (2, 32, 1, (5, 9, 19)),
+                                                 (4, 16, 2, (9, 9, 9))])
+def test_conv3d_fwd_pair_equals_two_convs(dtype, cin, cout, stride, sp):
+    """segmi_conv3d_fwd_pair (subunit 0 + residual conv of the first ResidualUnit in one launch)
+    gives the very bits of two segmi_conv3d_fwd calls, statistics included."""
+    n = 2
+    x = rnd((n, cin) + sp, 301)
+    wa, wb = rnd((cout, cin, 3, 3, 3), 302, 0.3), rnd((cout, cin, 3, 3, 3), 303, 0.3)
+    ba, bb = rnd((cout,), 304, 0.1), rnd((cout,), 305, 0.1)
+    alpha = torch.tensor([0.2], device=DEV)
+    xd = to_ndhwc(x, dtype)
+    osp = tuple((s + 2 - 3) // stride + 1 for s in sp)
+    mk = lambda: torch.empty((n,) + osp + (cout,), dtype=dtype, device=DEV)
+    wad, wbd, bad, bbd = wa.to(DEV), wb.to(DEV), ba.to(DEV), bb.to(DEV)
+    assert ops.conv3d_pair_ok(xd, mk(), mk())
+    for act_a, with_stats in ((None, True), (alpha, False)):
+        ya, yb, pa, pb = mk(), mk(), mk(), mk()
+        rows = ops.conv3d_stats_rows(xd, ya, 3, stride)
+        st1 = torch.zeros((rows, 2, cout), device=DEV) if with_stats else None
+        st2 = torch.zeros((rows, 2, cout), device=DEV) if with_stats else None
+        ops.conv3d_fwd(xd, ya, None, wad, 0, bad, 3, stride, prelu_alpha=act_a, stats=st1)
+        ops.conv3d_fwd(xd, yb, None, wbd, 0, bbd, 3, stride)
+        ops.conv3d_fwd_pair(xd, pa, wad, bad, pb, wbd, bbd, stride, prelu_alpha_a=act_a, stats_a=st2)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, pa) and torch.equal(yb, pb)
+        if with_stats:
+            real = rows - 131                                      # rows behind are reduction scratch
+            assert torch.equal(st1[:real], st2[:real])
+    ref = F.conv3d(q(x, dtype), q(wb, dtype), bb, stride=stride, padding=1)
+    assert relerr(from_ndhwc(pb), ref) < tol(dtype)
+    # MFMA-shaped layers do not qualify
+    big = torch.empty((1, 4, 4, 4, 16), dtype=dtype, device=DEV)
+    assert not ops.conv3d_pair_ok(big, big.clone(), big.clone())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3d_epilogue_prelu_residual_and_views(dtype):
     """PReLU + residual epilogue, reading from / writing into channel slices (concat by offset)."""
     n, cin, cout, sp = 1, 16, 16, (6, 10, 18)
