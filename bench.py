@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--volume", type=int, default=512, help="infer: cubic volume extent")
     ap.add_argument("--overlap", type=float, default=0.5)
+    ap.add_argument("--sw-batch", type=int, default=4, help="infer: windows per predictor call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=128)
     return ap.parse_args()
@@ -181,7 +182,7 @@ def main():
 
         def run():
             with torch.no_grad():
-                return sliding_window_inference(vol, (args.size,) * 3, 4, net, overlap=args.overlap,
+                return sliding_window_inference(vol, (args.size,) * 3, args.sw_batch, net, overlap=args.overlap,
                                                 return_labels=True)
         for _ in range(args.warmup):
             run()
@@ -195,7 +196,7 @@ def main():
         units = args.steps
         metric, unit = "sliding-window infer vols/s", "volumes/s"
         cfg = {"workload": f"sliding_window_inference of one {V}^3 volume, roi {args.size}^3, overlap "
-                           f"{args.overlap}, sw_batch 4, {K} labels, {args.precision}, gather+forward+blend+argmax on device",
+                           f"{args.overlap}, sw_batch {args.sw_batch}, {K} labels, {args.precision}, gather+forward+blend+argmax on device",
                "parallelism": f"replicas{world}"}
         kern_units = None
 

@@ -50,8 +50,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = static_cast<__bf16>(f);  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
   return __builtin_bit_cast(bf16_t, b);
 }
+typedef float f32x2_cv __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_cv __attribute__((ext_vector_type(2)));
+// both halves in ONE v_cvt_pk_bf16_f32 (two scalar conversions cost 2 cvt + and + or_sdwa)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  const f32x2_cv f{lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_cv));
 }
 
 template <typename T> struct Elem;

@@ -24,6 +24,7 @@ struct ConvParams {
   int N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, ldi, ldo, ldr;
   int tz, ty, tx;
   int nchunks, ntiles_total;
+  int dbg;   // diagnostics only (SEGMI_RING2_DBG): 1 = no staging loads, 2 = no stores, 4 = no MFMA loop
 };
 
 template <typename T, int CK, int KS, int S, int TD, int TH, int TW>

@@ -23,7 +23,9 @@
 
 namespace segmi {
 
-template <typename T, int CK, int NT>
+// PLAIN: no PReLU and no statistics (the two full-resolution launches of a training step and every
+// input-gradient launch): the epilogue is bias + residual + convert only
+template <typename T, int CK, int NT, bool PLAIN>
 __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvParams p) {
   static_assert(sizeof(T) == 2, "bf16 only");
   using G = RingGeom<T, CK>;
@@ -121,9 +123,10 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     if (p.bias) bias4[jt] = *reinterpret_cast<const f32x4*>(p.bias + (nt0 + jt) * 16 + 4 * g);
     touch_v(bias4[jt]);
   }
-  const bool has_alpha = p.alpha != nullptr;
+  const bool has_alpha = !PLAIN && p.alpha != nullptr;
   float alpha = has_alpha ? *p.alpha : 0.f;
   touch_s(alpha);
+  const bool want_stats = !PLAIN && p.stats != nullptr;
   f32x4 ssum[NT], ssq[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) { ssum[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     for (int pl = 0; pl < G::TD; ++pl) {
       const int z = z0 + zb + 5 + pl;
       const char* pp = img + (int64_t)z * plane_stride;
-      const bool zok = more && z < p.Di;
+      const bool zok = more && z < p.Di && !(p.dbg & 1);
 #pragma unroll
       for (int q = 0; q < NLP; ++q) {
         stg[pl][q] = frag_t{0u, 0u, 0u, 0u};
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     };
     issue(0, a[0]);
     issue(1, a[1]);
+    if (!(p.dbg & 4))
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       if (it + 2 < NIT) issue(it + 2, a[(it + 2) % 3]);
@@ -285,8 +289,8 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           f32x4 v = acc[zi][ro][jt] + bias4[jt];
-          if (oz < p.Do && row_ok[ro]) {
-            if (p.stats) { ssum[jt] += v; ssq[jt] += v * v; }
+          if (oz < p.Do && row_ok[ro] && !(p.dbg & 2)) {
+            if (want_stats) { ssum[jt] += v; ssq[jt] += v * v; }
             if (has_alpha) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     __syncthreads();
   }
 
-  if (p.stats) {
+  if (want_stats) {
     float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]  (ring no longer needed)
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -323,11 +327,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   }
 }
 
-template <typename T, int CK, int NT>
-static int launch_conv_ring2_cfg(ConvParams p, hipStream_t st) {
+template <typename T, int CK, int NT, bool PLAIN>
+static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   using G = RingGeom<T, CK>;
   constexpr int dt = SEGMI_BF16;
   p.tz = conv_ring_zsplit(dt, p.Cin, 3, 1, p.N, p.Do, p.Ho, p.Wo);
+  static const int dbg = getenv("SEGMI_RING2_DBG") ? atoi(getenv("SEGMI_RING2_DBG")) : 0;
+  p.dbg = dbg;
   p.ty = cdiv(p.Ho, G::TH);
   p.tx = cdiv(p.Wo, G::TW);
   // 32-bit byte offsets inside one input / output plane
@@ -335,7 +341,7 @@ static int launch_conv_ring2_cfg(ConvParams p, hipStream_t st) {
                       (int64_t)p.Ho * p.Wo * (p.ldr > 0 ? p.ldr : 1) < (1ll << 31),
                   "conv3d: plane too large for the ring kernel's 32-bit offsets");
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
-  auto kern = conv_ring2_kernel<T, CK, NT>;
+  auto kern = conv_ring2_kernel<T, CK, NT, PLAIN>;
   static bool attr_done = false;
   if (!attr_done && G::LDS_BYTES > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -345,6 +351,12 @@ static int launch_conv_ring2_cfg(ConvParams p, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(ring2)");
   return SEGMI_OK;
+}
+
+template <typename T, int CK, int NT>
+static int launch_conv_ring2_cfg(const ConvParams& p, hipStream_t st) {
+  if (!p.alpha && !p.stats) return launch_conv_ring2_k<T, CK, NT, true>(p, st);
+  return launch_conv_ring2_k<T, CK, NT, false>(p, st);
 }
 
 // bf16 ring layers: 16 -> 16*m and 32 -> 32*m
