@@ -1,5 +1,5 @@
 #!/bin/bash
-for d in 0 3 4; do SEGMI_RING2_DBG=$d python scripts/ring2_diag.py 8 2>&1 | tail -1; done
+python scripts/ring2_diag.py 8 2>&1 | tail -1
 python -m pytest tests -x -q -m gpu > gpurun_out/t_r2.log 2>&1; tail -2 gpurun_out/t_r2.log
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-260
 python bench.py --workload infer --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200

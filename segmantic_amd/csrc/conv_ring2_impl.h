@@ -21,6 +21,15 @@
 #pragma once
 #include "conv_ring_impl.h"
 
+// Time-split diagnostic (build with -DSEGMI_RING2_DIAG, run with SEGMI_RING2_DBG=bits: 1 = no staging
+// loads, 2 = no stores, 4 = no MFMA loop; scripts/ring2_diag.py).  Compiled out of the product build:
+// the extra live flag costs the 32 -> 64 variant its last free registers.
+#ifdef SEGMI_RING2_DIAG
+#define RING2_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define RING2_DBG(p, bit) false
+#endif
+
 namespace segmi {
 
 // PLAIN: no PReLU and no statistics (the two full-resolution launches of a training step and every
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     for (int pl = 0; pl < G::TD; ++pl) {
       const int z = z0 + zb + 5 + pl;
       const char* pp = img + (int64_t)z * plane_stride;
-      const bool zok = more && z < p.Di && !(p.dbg & 1);
+      const bool zok = more && z < p.Di && !RING2_DBG(p, 1);
 #pragma unroll
       for (int q = 0; q < NLP; ++q) {
         stg[pl][q] = frag_t{0u, 0u, 0u, 0u};
@@ -192,19 +201,22 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     int pofs[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c) % G::R) * G::PLANE_B + wrow;
-    // software pipeline over the (plane, k-step) iterations, fragments two iterations ahead
-    frag_t a[3][2];
+    // software pipeline over the (plane, k-step) iterations, fragments PD iterations ahead (an
+    // iteration is 2 - 6 MFMAs = 32 - 96 clk against >= 128 clk of loaded LDS latency; the depth is
+    // what the variant's register budget allows)
+    constexpr int PD = CK == 16 ? (PLAIN ? 4 : 3) : (NT == 1 ? 4 : 2);
+    frag_t a[PD + 1][2];
     auto issue = [&](int it, frag_t (&dst)[2]) {
       const int c = it / J, j = it % J;
       dst[0] = *reinterpret_cast<const frag_t*>(smem + pofs[c] + laneoff[j]);
       dst[1] = *reinterpret_cast<const frag_t*>(smem + pofs[c] + laneoff[j] + G::HW * G::ROWB);
     };
-    issue(0, a[0]);
-    issue(1, a[1]);
-    if (!(p.dbg & 4))
+#pragma unroll
+    for (int q = 0; q < PD; ++q) issue(q, a[q]);
+    if (!RING2_DBG(p, 4))
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (it + 2 < NIT) issue(it + 2, a[(it + 2) % 3]);
+      if (it + PD < NIT) issue(it + PD, a[(it + PD) % (PD + 1)]);
       __builtin_amdgcn_sched_barrier(0);
       const int c = it / J, j = it % J;
 #pragma unroll
@@ -213,8 +225,8 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
         if (zi >= 0 && zi < 4) {
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) {
-            acc[zi][0][jt] = mma16<T>(wreg[kd][j][jt], a[it % 3][0], acc[zi][0][jt]);
-            acc[zi][1][jt] = mma16<T>(wreg[kd][j][jt], a[it % 3][1], acc[zi][1][jt]);
+            acc[zi][0][jt] = mma16<T>(wreg[kd][j][jt], a[it % (PD + 1)][0], acc[zi][0][jt]);
+            acc[zi][1][jt] = mma16<T>(wreg[kd][j][jt], a[it % (PD + 1)][1], acc[zi][1][jt]);
           }
         }
       }
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           f32x4 v = acc[zi][ro][jt] + bias4[jt];
-          if (oz < p.Do && row_ok[ro] && !(p.dbg & 2)) {
+          if (oz < p.Do && row_ok[ro] && !RING2_DBG(p, 2)) {
             if (want_stats) { ssum[jt] += v; ssq[jt] += v * v; }
             if (has_alpha) {
 #pragma unroll

@@ -306,3 +306,27 @@ def test_augmentation_draws_follow_the_reference_distributions():
     assert np.all(hist[1][:, 0] == 0) and np.all(hist[1][:, -1] == 1)
     assert bias[1].shape == (64, 20) and bias[1].min() >= 0 and bias[1].max() < 0.1
     assert con[1].min() >= 0.5 and con[1].max() <= 4.5
+
+
+def test_hot_kernels_do_not_spill_registers(tmp_path):
+    """Reads the code-object metadata of the built library: no kernel may spill VGPRs to scratch
+    (a spilling MFMA kernel runs several times slower and nothing else would notice).  The f32
+    z-marching ring (parity path, not the measured one) is the documented exception."""
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = ROOT / "segmantic_amd" / "csrc" / "libsegmi.so"
+    if not (so.exists() and Path(f"{llvm}/llvm-objdump").exists()):
+        pytest.skip("library or llvm tools not present")
+    shutil.copy(so, tmp_path / "lib.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, check=True,
+                   capture_output=True)
+    spilled, seen = [], 0
+    for f in sorted(tmp_path.glob("lib.so.*gfx950")):
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(f)], capture_output=True,
+                               text=True).stdout
+        for name, cnt in re.findall(r"\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+            seen += 1
+            if int(cnt) and "conv_ring_mfma_kernelIf" not in name:
+                spilled.append((name, int(cnt)))
+    assert seen > 100, seen
+    assert not spilled, spilled
