@@ -191,13 +191,8 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       }
     }
     // ---- compute: input plane c (z = zb - 1 + c) lives in ring slot (zb + c) % R
+    // (no zero-initialisation: the first MFMA into an accumulator takes the literal 0 as C)
     f32x4 acc[4][2][NT];
-#pragma unroll
-    for (int zi = 0; zi < 4; ++zi)
-#pragma unroll
-      for (int ro = 0; ro < 2; ++ro)
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) acc[zi][ro][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     int pofs[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c) % G::R) * G::PLANE_B + wrow;
@@ -225,8 +220,10 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
         if (zi >= 0 && zi < 4) {
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) {
-            acc[zi][0][jt] = mma16<T>(wreg[kd][j][jt], a[it % (PD + 1)][0], acc[zi][0][jt]);
-            acc[zi][1][jt] = mma16<T>(wreg[kd][j][jt], a[it % (PD + 1)][1], acc[zi][1][jt]);
+            const bool first = kd == 0 && j == 0;     // plane c = zi, k-step 0 opens the sum
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[zi][0][jt] = mma16<T>(wreg[kd][j][jt], a[it % (PD + 1)][0], first ? zero : acc[zi][0][jt]);
+            acc[zi][1][jt] = mma16<T>(wreg[kd][j][jt], a[it % (PD + 1)][1], first ? zero : acc[zi][1][jt]);
           }
         }
       }

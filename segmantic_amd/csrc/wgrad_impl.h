@@ -18,6 +18,17 @@
 #pragma once
 #include "common.h"
 
+// Time-split diagnostic (build with -DSEGMI_WGRAD_DIAG, run with SEGMI_WGRAD_DBG=bits: 1 = no global
+// loads, 4 = no LDS-read / MFMA loop; scripts/wgrad_diag.py).  Measured on the 128^3 x 8, 16 x 16 layer
+// (cold caches, us): all 444, no loads 316, no MFMA loop 254, neither 137 -- the three phases of a
+// tile barely overlap at 2 workgroups per CU; the MFMA-loop phase sits at the LDS instruction
+// rate (2 ds_read_b64_tr_b16 per operand, ~2.4 clk each, 2.3 per MFMA).
+#ifdef SEGMI_WGRAD_DIAG
+#define WGRAD_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define WGRAD_DBG(p, bit) false
+#endif
+
 namespace segmi {
 
 struct WgradParams {
@@ -28,6 +39,7 @@ struct WgradParams {
   int tz, ty, tx;
   int ntiles;
   int ci_chunks;
+  int dbg;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -147,14 +159,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     for (int k = 0; k < NLY; ++k) {        // dY tile [NV][16*CTO]
       const unsigned pk = y_pk[k];
       ry[k] = frag_t{0u, 0u, 0u, 0u};
-      if ((pk & 255u) < lz && ((pk >> 8) & 255u) < ly && (pk >> 16) < lx)
+      if ((pk & 255u) < lz && ((pk >> 8) & 255u) < ly && (pk >> 16) < lx && !WGRAD_DBG(p, 1))
         ry[k] = *reinterpret_cast<const frag_t*>(ybase + (unsigned)y_goff[k]);
     }
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {        // X halo tile [HD*HH*HW][16*CTI]
       const unsigned pk = x_pk[k];
       rx[k] = frag_t{0u, 0u, 0u, 0u};
-      if (pk != 0xffffffffu && (unsigned)((int)(pk & 255u) + iz0) < (unsigned)p.Dx &&
+      if (pk != 0xffffffffu && !WGRAD_DBG(p, 1) && (unsigned)((int)(pk & 255u) + iz0) < (unsigned)p.Dx &&
           (unsigned)((int)((pk >> 8) & 255u) + iy0) < (unsigned)p.Hx &&
           (unsigned)((int)(pk >> 16) + ix0) < (unsigned)p.Wx)
         rx[k] = *reinterpret_cast<const frag_t*>(xbase + (unsigned)x_goff[k]);
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     __syncthreads();
     if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
 
+    if (!WGRAD_DBG(p, 4))
 #pragma unroll
     for (int lg = 0; lg < G::NL / G::LPG; ++lg) {
       frag_t af[CTO];
@@ -270,6 +283,8 @@ static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
                       (int64_t)TD * p.Hy * p.Wy * p.ldy * (int64_t)sizeof(T) < (1ll << 31),
                   "conv3d_wgrad: plane too large for the MFMA kernel's 32-bit tile offsets");
   p.ci_chunks = p.Cin / (16 * CTI);
+  static const int dbg = getenv("SEGMI_WGRAD_DBG") ? atoi(getenv("SEGMI_WGRAD_DBG")) : 0;
+  p.dbg = dbg;
   const int co_chunks = p.Cout / (16 * CTO);
   dim3 grid((unsigned)gx_hint, (unsigned)(co_chunks * p.ci_chunks));
   auto kern = wgrad_mfma_kernel<T, KS, S, CTO, CTI, TD, TH, TW>;
@@ -285,10 +300,10 @@ static int launch_wgrad_cfg(WgradParams p, int gx_hint, hipStream_t st) {
 }
 
 // how many voxel-range workgroups (= partial slabs) the MFMA path uses
-static inline int wgrad_tiles(const segmi_act* dy, int stride) {
+static inline int wgrad_tiles(const segmi_act* dy, int stride, bool one_block) {
   const bool wide = dy->w > 8;
   int td, th, tw;
-  if (stride == 1) { td = wide ? 2 : 4; th = 8; tw = wide ? 16 : 8; }
+  if (stride == 1) { td = wide && !one_block ? 2 : 4; th = 8; tw = wide ? 16 : 8; }
   else { td = 2; th = wide ? 4 : 8; tw = wide ? 16 : 8; }
   return dy->n * cdiv(dy->d, td) * cdiv(dy->h, th) * cdiv(dy->w, tw);
 }
@@ -313,7 +328,7 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
   const int target = cto * cti == 1 ? 512 : 256;
   int gx = target / chunks;
   if (gx < 1) gx = 1;
-  const int nt = wgrad_tiles(dy, stride);
+  const int nt = wgrad_tiles(dy, stride, cto * cti == 1);
   return gx < nt ? gx : nt;
 }
 
@@ -346,7 +361,11 @@ static int launch_wgrad_mfma_t(const WgradParams& p, int ksize, int stride, int 
       if (ct == 21) WG_CFG(3, 2, 2, 1);
     }
   }
-  if (stride == 1) WG_CFG(3, 1, 1, 1);
+  // 16 x 16 channel block (144 VGPRs, 50 KB of LDS): 4 output planes per tile halve the per-tile
+  // overhead (barriers, tile decode, LDS commit) and take the X halo from 2.8x to 2.1x
+  if (stride == 1)
+    return wide ? launch_wgrad_cfg<T, 3, 1, 1, 1, 4, 8, 16>(p, gx, st)
+                : launch_wgrad_cfg<T, 3, 1, 1, 1, 4, 8, 8>(p, gx, st);
   WG_CFG(3, 2, 1, 1);
 }
 #undef WG_CFG
