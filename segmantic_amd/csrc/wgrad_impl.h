@@ -323,7 +323,7 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
   const int cto = ct / 10, cti = ct % 10;
   const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
   // workgroups wanted = a multiple of the 256 CUs; one per CU once the kernel holds > 1 channel
-  // tile (200-400 VGPRs, 55-110 KB slabs).  Measured on MI355X (scripts/wg_sweep.sh): 1x1 blocks
+  // tile (200-400 VGPRs, 55-110 KB slabs).  Measured on MI355X: 1x1 blocks
   // 704/508/540/608 us at 256/512/1024/2048 workgroups, 2x2 blocks 125/198/348 us at 256/512/1024.
   const int target = cto * cti == 1 ? 512 : 256;
   int gx = target / chunks;
