@@ -166,7 +166,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         units = args.batch * args.size ** 3 * args.steps
-        metric, unit = "3D UNet train voxels/s on 128^3 bf16", "voxels/s"
+        metric, unit = f"3D UNet train voxels/s on {args.size}^3 {args.precision}", "voxels/s"
         workload = (f"training_step (fwd + Dice + bwd + Adam) of the 5-level residual UNet, "
                     f"batch {args.batch} x 1ch x {args.size}^3, {K} labels, {args.precision}")
         kern_units = args.batch * args.size ** 3
