@@ -82,10 +82,26 @@ int segmi_wpack_batch(int dtype, const segmi_wpack_desc* descs_host, int ndesc,
  * Replaces torch.nn.Conv3d under monai UNet, src/segmantic/seg/monai_unet.py:114-124,341. */
 int segmi_conv3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                             int stride);
+/* Optional input transform of a convolution (forward and weight gradient): the consumer applies the
+ * PRODUCER layer's BatchNorm-apply + PReLU, in' = prelu(in * scale[c] + shift[c]) rounded to the
+ * storage type, while it stages its input, so the normalised activation is never written to HBM
+ * (zero padding stays zero; an identity residual `residual == in` adds in').  scale / shift: device
+ * f32[cin] as written by segmi_bn_finalize; prelu_alpha: device f32* or NULL.  Bit-identical to
+ * running segmi_bn_act_fwd first.  segmi_conv3d_in_affine_ok() says whether the layer's kernels
+ * implement it (bf16 z-marching ring forward + MFMA weight gradient); pass NULL otherwise.
+ * Replaces the separate ADN pass between two torch modules of monai UNet, monai_unet.py:114-124. */
+typedef struct segmi_in_affine {
+  const float* scale;
+  const float* shift;
+  const float* prelu_alpha;
+} segmi_in_affine;
+int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                              int stride);
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
-                     float* stats_partials, int ksize, int stride, void* stream);
+                     float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
+                     void* stream);
 /* The first ResidualUnit of the network convolves its (<= 4 channel) input twice with the same
  * geometry: subunit 0 (k3, stride s) and the residual convolution (k3, stride s).  One launch
  * stages the input once and produces both:  out_a = prelu_a(conv_a(in) + bias_a) with optional
@@ -117,7 +133,8 @@ int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, cons
 int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_act* dy,
                                      int ksize, int stride);
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
-                       float* db, int ksize, int stride, void* workspace, void* stream);
+                       float* db, int ksize, int stride, void* workspace,
+                       const segmi_in_affine* in_tf /* transform of x, nullable */, void* stream);
 /* bias gradient only: db[c] = sum over voxels of dy */
 int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream);
 

@@ -37,6 +37,12 @@ class WpackDesc(C.Structure):
                 ("ksize", C.c_int32)]
 
 
+class InAffine(C.Structure):
+    """``segmi_in_affine``: BatchNorm-apply + PReLU of the producer, applied by the consumer's staging."""
+
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("prelu_alpha", C.c_void_p)]
+
+
 _P = C.c_void_p
 _AP = C.POINTER(Act)
 _i = C.c_int
@@ -52,13 +58,14 @@ SIGNATURES = {
     "segmi_wpack": (_i, [_i, _i, _P, _P, _i, _i, _i, _P, _P]),
     "segmi_wpack_batch": (_i, [_i, C.POINTER(WpackDesc), _i, _P, _i, _P]),
     "segmi_conv3d_stats_rows": (_i, [_i, _AP, _AP, _i, _i]),
-    "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, _P]),
+    "segmi_conv3d_in_affine_ok": (_i, [_i, _AP, _AP, _i, _i]),
+    "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, C.POINTER(InAffine), _P]),
     "segmi_conv3d_pair_ok": (_i, [_i, _AP, _AP, _AP]),
     "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),
     "segmi_convT3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P]),
     "segmi_conv3d_wgrad_workspace": (_i64, [_i, _AP, _AP, _i, _i]),
-    "segmi_conv3d_wgrad": (_i, [_i, _AP, _AP, _P, _P, _i, _i, _P, _P]),
+    "segmi_conv3d_wgrad": (_i, [_i, _AP, _AP, _P, _P, _i, _i, _P, C.POINTER(InAffine), _P]),
     "segmi_bias_grad": (_i, [_i, _AP, _P, _P, _P]),
     "segmi_bn_stats_rows": (_i, [_AP]),
     "segmi_bn_stats": (_i, [_i, _AP, _P, _P]),

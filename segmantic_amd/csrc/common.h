@@ -124,6 +124,26 @@ template <typename V> __device__ __forceinline__ void touch_v(V& v) { asm volati
 // scalar variant for wave-uniform values; "+v" because hipcc may already hold them in a VGPR
 __device__ __forceinline__ void touch_s(float& v) { asm volatile("" : "+v"(v)); }
 
+// BatchNorm-apply + PReLU of the PRODUCER layer on 8 bf16 channels of one voxel, done while the
+// consumer stages its input (segmi_in_affine): z = fma(x, scale, shift); z = z > 0 ? z : alpha * z,
+// rounded to bf16 exactly as bn_act_fwd stores it, so a consumer that transforms on the fly sees
+// the very bits the separate pass would have written.  sc / sh: the 8 channels of this 16-byte chunk.
+__device__ __forceinline__ frag_t bn_prelu_bf16x8(const frag_t raw, const float (&sc)[8], const float (&sh)[8],
+                                                  const float alpha, const bool has_alpha) {
+  frag_t o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float z0 = fmaf(__uint_as_float(raw[q] << 16), sc[2 * q], sh[2 * q]);
+    float z1 = fmaf(__uint_as_float(raw[q] & 0xffff0000u), sc[2 * q + 1], sh[2 * q + 1]);
+    if (has_alpha) {
+      z0 = z0 > 0.f ? z0 : alpha * z0;
+      z1 = z1 > 0.f ? z1 : alpha * z1;
+    }
+    o[q] = pack_bf16x2(z0, z1);
+  }
+  return o;
+}
+
 // sum over the 16 lanes that share (lane>>4): result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
   v += __shfl_xor(v, 1);

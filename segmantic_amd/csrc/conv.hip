@@ -176,10 +176,21 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
                         stride, (hipStream_t)stream, out_b, w_b, bias_b);
 }
 
+int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                              int stride) {
+  if (!act_ok(in) || !act_ok(out) || dtype != SEGMI_BF16 || !mfma_ok(in->c, out->c)) return 0;
+  // forward: the bf16 z-marching ring; weight gradient: the MFMA kernel (any channel blocking)
+  return ksize == 3 && stride == 1 && conv_ring_ok(dtype, in->c, ksize, stride, out) ? 1 : 0;
+}
+
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
-                     float* stats_partials, int ksize, int stride, void* stream) {
+                     float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
+                     void* stream) {
+  if (in_tf)
+    SEGMI_CHECK_ARG(in_tf->scale && in_tf->shift && segmi_conv3d_in_affine_ok(dtype, in, out, ksize, stride),
+                    "conv3d: this layer cannot take an input transform (ask segmi_conv3d_in_affine_ok)");
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "conv3d: bad dtype %d", dtype);
   SEGMI_CHECK_ARG(act_ok(in) && act_ok(out), "conv3d: bad activation view");
   SEGMI_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2),
@@ -213,6 +224,7 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
     p.ldr = residual ? residual->ld : 0;
     p.nchunks = in->c / pick_ck(dtype, in->c);
     p.ntiles_total = out->c / 16;
+    if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
     return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st)
                               : conv_mfma_bf16(p, ksize, stride, st);
   }

@@ -24,6 +24,11 @@ struct ConvParams {
   int N, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, ldi, ldo, ldr;
   int tz, ty, tx;
   int nchunks, ntiles_total;
+  // optional input transform (segmi_in_affine): the producer's BatchNorm-apply + PReLU is applied
+  // while the input is staged; kernels that do not implement it must not be dispatched with it
+  const float* in_scale;
+  const float* in_shift;
+  const float* in_alpha;
   int dbg;   // diagnostics only (SEGMI_RING2_DBG): 1 = no staging loads, 2 = no stores, 4 = no MFMA loop
 };
 

@@ -110,6 +110,24 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     l_off[q] = i < G::PLANE_CHUNKS ? row * G::ROWB + ch * 16 : -1;
     g_off[q] = ok ? (y * p.Wi + x) * p.ldi * (int)sizeof(T) + ch * 16 : -1;
   }
+  // optional input transform: scale / shift of this thread's channel chunk (every 16-byte chunk a
+  // thread stages has the same channel offset: 256 % CPR == 0).  Kept in LDS behind the ring and
+  // re-read where a chunk is committed -- no registers held across the MFMA loop (holding the 16
+  // values in registers for a whole commit phase makes every variant spill).
+  const bool in_tf = p.in_scale != nullptr;
+  const bool in_act = in_tf && p.in_alpha != nullptr;
+  float* tfs = reinterpret_cast<float*>(smem + G::LDS_BYTES);   // [2][CK]
+  if (in_tf && tid < 2 * CK) tfs[tid] = tid < CK ? p.in_scale[tid] : p.in_shift[tid - CK];
+  float in_alpha = in_act ? *p.in_alpha : 0.f;
+  touch_s(in_alpha);
+  const int tf_ch = (tid % G::CPR) * 8;
+  auto transform = [&](frag_t v) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
+    return bn_prelu_bf16x8(v, sc, sh, in_alpha, in_act);
+  };
+  if (in_tf) __syncthreads();
   // prologue: planes z0-1 .. z0+4 -> ring slots 0 .. 5
 #pragma unroll
   for (int pl = 0; pl < 6; ++pl) {
@@ -118,8 +136,9 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
     for (int q = 0; q < NLP; ++q) {
       frag_t val = frag_t{0u, 0u, 0u, 0u};
-      if ((unsigned)z < (unsigned)p.Di && g_off[q] >= 0)
-        val = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+      const bool inside = (unsigned)z < (unsigned)p.Di && g_off[q] >= 0;
+      if (inside) val = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+      if (in_tf && inside) val = transform(val);        // zero padding stays zero
       if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + pl * G::PLANE_B + l_off[q]) = val;
     }
   }
@@ -234,9 +253,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
       for (int pl = 0; pl < G::TD; ++pl) {
         const int slot = (zb + 6 + pl) % G::R;
+        const bool zin = z0 + zb + 5 + pl < p.Di;
 #pragma unroll
-        for (int q = 0; q < NLP; ++q)
-          if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = stg[pl][q];
+        for (int q = 0; q < NLP; ++q) {
+          frag_t val = stg[pl][q];
+          if (in_tf && zin && g_off[q] >= 0) val = transform(val);
+          if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = val;
+        }
       }
     }
     // every staging register is dead from here on; say so on ALL control-flow paths (touch_v)
@@ -352,12 +375,12 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
   auto kern = conv_ring2_kernel<T, CK, NT, PLAIN>;
   static bool attr_done = false;
-  if (!attr_done && G::LDS_BYTES > 64 * 1024) {
+  if (!attr_done && G::LDS_BYTES + 2 * CK * 4 > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + 2 * CK * 4);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES + 2 * CK * 4, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(ring2)");
   return SEGMI_OK;
 }

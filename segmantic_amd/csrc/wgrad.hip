@@ -140,7 +140,12 @@ int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, 
 }
 
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
-                       float* db, int ksize, int stride, void* workspace, void* stream) {
+                       float* db, int ksize, int stride, void* workspace,
+                       const segmi_in_affine* in_tf, void* stream) {
+  if (in_tf)
+    SEGMI_CHECK_ARG(in_tf->scale && in_tf->shift && dtype == SEGMI_BF16 && act_ok(x) && act_ok(dy) &&
+                        wg_mfma_ok(dtype, x, dy, ksize),
+                    "wgrad: an input transform needs the bf16 MFMA kernel");
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "wgrad: bad dtype");
   SEGMI_CHECK_ARG(act_ok(x) && act_ok(dy) && dw && workspace, "wgrad: bad arguments");
   SEGMI_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "wgrad: k/s");
@@ -159,6 +164,7 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
     p.x = x->data; p.dy = dy->data; p.partials = partials;
     p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
     p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
+    if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
     const int ct = wgrad_ct(dtype, x->c, dy->c);
     const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, slabs, st)
                                       : wgrad_mfma_bf16(p, ksize, stride, ct, slabs, st);

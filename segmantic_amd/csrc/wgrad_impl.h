@@ -40,6 +40,11 @@ struct WgradParams {
   int ntiles;
   int ci_chunks;
   int dbg;
+  // optional input transform of X (segmi_in_affine): the BatchNorm-apply + PReLU that produced the
+  // forward input is applied while the X tile is committed to LDS (bf16 only)
+  const float* in_scale;
+  const float* in_shift;
+  const float* in_alpha;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   // Register-staged software pipeline: the global loads of tile t+1 are issued before the MFMA
   // phase of tile t and land in LDS after it (global latency hides under compute).
   constexpr int NLY = (G::NV * G::YCPR + 255) / 256, NLX = (G::XROWS * G::XCPR + 255) / 256;
+  static_assert(NLX <= 32, "one validity bit per staged X chunk");
   frag_t ry[NLY], rx[NLX];
   // Step-invariant per-lane descriptors: 32-bit byte offset inside a tile and packed tile-local
   // coordinates.  Per tile only a wave-uniform base pointer and uniform limits change, so a load
@@ -142,6 +148,18 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     x_goff[k] = ((hz * p.Hx + hy) * p.Wx + hx) * p.ldx * (int)sizeof(T) + ch * 16;
     x_pk[k] = i < G::XROWS * G::XCPR ? (unsigned)(hz | (hy << 8) | (hx << 16)) : 0xffffffffu;
   }
+  // input transform: this thread's X chunks all sit at channel offset (tid % XCPR) * 8 of the block
+  const bool in_tf = sizeof(T) == 2 && p.in_scale != nullptr;
+  const bool in_act = in_tf && p.in_alpha != nullptr;
+  float tsc[8], tsh[8];
+  float in_alpha = in_act ? *p.in_alpha : 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = ci0 + (tid % G::XCPR) * 8 + e;
+    tsc[e] = in_tf ? p.in_scale[ch] : 1.f;
+    tsh[e] = in_tf ? p.in_shift[ch] : 0.f;
+  }
+  unsigned xin = 0u;   // bit k: rx[k] of the pending tile lies inside the volume (zero padding stays 0)
   auto fetch = [&](int tile) {
     int t = tile;
     const int txi = t % p.tx; t /= p.tx;
@@ -166,10 +184,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     for (int k = 0; k < NLX; ++k) {        // X halo tile [HD*HH*HW][16*CTI]
       const unsigned pk = x_pk[k];
       rx[k] = frag_t{0u, 0u, 0u, 0u};
-      if (pk != 0xffffffffu && !WGRAD_DBG(p, 1) && (unsigned)((int)(pk & 255u) + iz0) < (unsigned)p.Dx &&
+      const bool inside = pk != 0xffffffffu && !WGRAD_DBG(p, 1) && (unsigned)((int)(pk & 255u) + iz0) < (unsigned)p.Dx &&
           (unsigned)((int)((pk >> 8) & 255u) + iy0) < (unsigned)p.Hx &&
-          (unsigned)((int)(pk >> 16) + ix0) < (unsigned)p.Wx)
-        rx[k] = *reinterpret_cast<const frag_t*>(xbase + (unsigned)x_goff[k]);
+          (unsigned)((int)(pk >> 16) + ix0) < (unsigned)p.Wx;
+      if (inside) rx[k] = *reinterpret_cast<const frag_t*>(xbase + (unsigned)x_goff[k]);
+      if (in_tf) xin = inside ? (xin | (1u << k)) : (xin & ~(1u << k));
     }
   };
   auto commit = [&]() {
@@ -182,8 +201,13 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {
       const int i = tid + 256 * k;
-      if (i < G::XROWS * G::XCPR)
-        *reinterpret_cast<frag_t*>(xsm + (i / G::XCPR) * G::XROWB + (i % G::XCPR) * 16) = rx[k];
+      if (i < G::XROWS * G::XCPR) {
+        frag_t val = rx[k];
+        if constexpr (sizeof(T) == 2) {
+          if (in_tf && ((xin >> k) & 1u)) val = bn_prelu_bf16x8(val, tsc, tsh, in_alpha, in_act);
+        }
+        *reinterpret_cast<frag_t*>(xsm + (i / G::XCPR) * G::XROWB + (i % G::XCPR) * 16) = val;
+      }
     }
   };
   if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);

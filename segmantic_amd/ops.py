@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SEGMI_BF16, SEGMI_F32, Act, check, lib
+from ._lib import SEGMI_BF16, SEGMI_F32, Act, InAffine, check, lib
 
 _DT = {torch.float32: SEGMI_F32, torch.bfloat16: SEGMI_BF16}
 
@@ -129,13 +129,31 @@ def conv3d_stats_rows(x, y, ksize, stride) -> int:
                                            stride))
 
 
+def _in_affine(in_tf):
+    """(scale, shift, prelu_alpha | None) device tensors -> segmi_in_affine (or NULL)"""
+    if in_tf is None:
+        return None
+    scale, shift, alpha = in_tf
+    for t in (scale, shift):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("in_tf: contiguous float32 scale / shift expected")
+    return C.byref(InAffine(_ptr(scale), _ptr(shift), _ptr(alpha)))
+
+
+def conv3d_in_affine_ok(x, y, ksize, stride) -> bool:
+    ax, ay = act(x), act(y)
+    return bool(lib.segmi_conv3d_in_affine_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
+
+
 def conv3d_fwd(x, y, packed, w_src, w_kind, bias, ksize, stride, prelu_alpha=None,
-               residual=None, stats=None) -> None:
+               residual=None, stats=None, in_tf=None) -> None:
+    """``in_tf`` = (scale, shift, alpha): the producer's BatchNorm-apply + PReLU is applied to ``x``
+    while it is staged (segmi_in_affine; only where ``conv3d_in_affine_ok``)."""
     ax, ay = act(x), act(y)
     ar = act(residual) if residual is not None else None
     check(lib.segmi_conv3d_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed),
                                _ptr(w_src), w_kind, _ptr(bias), _ptr(prelu_alpha), _ref(ar),
-                               _ptr(stats), ksize, stride, _stream()), "conv3d_fwd")
+                               _ptr(stats), ksize, stride, _in_affine(in_tf), _stream()), "conv3d_fwd")
 
 
 def conv3d_pair_ok(x, y_a, y_b) -> bool:
@@ -171,10 +189,11 @@ def conv3d_wgrad_workspace(x, dy, ksize, stride) -> int:
                                                 stride))
 
 
-def conv3d_wgrad(x, dy, dw, db, ksize, stride, workspace) -> None:
+def conv3d_wgrad(x, dy, dw, db, ksize, stride, workspace, in_tf=None) -> None:
     ax, ay = act(x), act(dy)
     check(lib.segmi_conv3d_wgrad(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(dw), _ptr(db),
-                                 ksize, stride, _ptr(workspace), _stream()), "conv3d_wgrad")
+                                 ksize, stride, _ptr(workspace), _in_affine(in_tf), _stream()),
+          "conv3d_wgrad")
 
 
 def bias_grad(dy, db, workspace) -> None:

@@ -520,7 +520,14 @@ class UNetEngine:
             return False
         return ops.conv3d_pair_ok(x, self._buf(dst_name, oshape + (c0.cout,)), out)
 
-    def _conv_train(self, conv: _Conv, x, y, bn: Optional[_BN]):
+    def _tf_ok(self, x, y, conv: _Conv) -> bool:
+        """the BatchNorm-apply + PReLU that would produce ``conv``'s input can be done by the conv
+        itself while it stages x (segmi_in_affine): no normalised copy of x is ever written"""
+        return (self.fuse_bn_apply and self.dtype == torch.bfloat16 and self.dropout_p <= 0.0
+                and not conv.transposed and conv.k == 3 and conv.stride == 1 and conv.mfma
+                and ops.conv3d_in_affine_ok(x, y, 3, 1))
+
+    def _conv_train(self, conv: _Conv, x, y, bn: Optional[_BN], in_tf=None):
         """raw conv (+bias) with fused statistics, then finalize into bn.*"""
         stats = None
         rows = 0
@@ -533,13 +540,13 @@ class UNetEngine:
                         conv.b, stats=stats)
         else:
             self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, x, y, conv.fwd_pack(), conv.w, 0,
-                        conv.b, conv.k, conv.stride, stats=stats)
+                        conv.b, conv.k, conv.stride, stats=stats, in_tf=in_tf)
         if bn is not None:
             count = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
             ops.bn_finalize(stats, rows, conv.cout, count, bn.gamma, bn.beta, bn.rm, bn.rv,
                             self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
 
-    def _wgrad(self, conv: _Conv, x, dy, need_bias: bool = True):
+    def _wgrad(self, conv: _Conv, x, dy, need_bias: bool = True, in_tf=None):
         """dW (and db) of `conv` given its forward input x and output gradient dy.
 
         ``need_bias=False`` for a conv that feeds a training-mode BatchNorm: dy is then the BN
@@ -568,7 +575,7 @@ class UNetEngine:
                 nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
                 ws = self._scratch_buf("wgrad", nbytes)
                 self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw,
-                            conv.gb if need_bias else None, conv.k, conv.stride, ws)
+                            conv.gb if need_bias else None, conv.k, conv.stride, ws, in_tf=in_tf)
 
     def _dgrad(self, conv: _Conv, dy, dx, residual=None):
         """dx = dgrad(conv, dy) (+ residual)."""
@@ -592,7 +599,11 @@ class UNetEngine:
                              bn.coef, dropout=bn.drop())
 
     # ------------------------------------------------------------------ residual unit
-    def _ru_fwd_train(self, ru, x, out):
+    def _ru_fwd_train(self, ru, x, out, in_tf=None):
+        """``in_tf``: x is the RAW output of the producer conv and (scale, shift, alpha) its pending
+        BatchNorm-apply + PReLU, which the first unit's conv applies on the fly (only for a unit
+        whose sole consumers of x are that conv, its weight gradient and an in-kernel identity
+        residual -- see ``_level_fwd``)."""
         pre = ru["prefix"]
         n, d, h, w = self._down_shape(x.shape, ru["stride"])
         cur = x
@@ -626,28 +637,42 @@ class UNetEngine:
                                 bn.rv, self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
                 saved[f"in{i}"] = cur
                 saved[f"r{i}"] = r
-                a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
-                ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
-                cur = a
+                nconv = ru["units"][i + 1][0]
+                if self._tf_ok(r, r, nconv) and nconv.cin == conv.cout and nconv.cout == conv.cout:
+                    in_tf = (bn.scale, bn.shift, bn.alpha)
+                    cur = r
+                else:
+                    a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
+                    ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
+                    cur = a
                 continue
             if bn is None:
                 # conv-only last unit (top of the net): out = conv(cur) + residual
                 self._join_branch(br)
                 self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, cur, out, conv.fwd_pack(), conv.w,
-                            0, conv.b, conv.k, conv.stride, residual=resid)
+                            0, conv.b, conv.k, conv.stride, residual=resid, in_tf=in_tf)
                 saved[f"in{i}"] = cur
+                saved[f"tf{i}"] = in_tf
                 break
             r = self._buf(f"{pre}.r{i}", (n, d, h, w, conv.cout))
-            self._conv_train(conv, cur, r, bn)
+            self._conv_train(conv, cur, r, bn, in_tf=in_tf)
             saved[f"in{i}"] = cur
             saved[f"r{i}"] = r
+            saved[f"tf{i}"] = in_tf
+            in_tf = None
             if last:
                 self._join_branch(br)
                 ops.bn_act_fwd(r, out, bn.scale, bn.shift, bn.alpha, residual=resid, dropout=bn.drop())
             else:
-                a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
-                ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
-                cur = a
+                nconv = ru["units"][i + 1][0]
+                if self._tf_ok(r, r, nconv) and nconv.cin == conv.cout and nconv.cout == conv.cout:
+                    # the next unit's conv (and its weight gradient) normalise r on the fly
+                    in_tf = (bn.scale, bn.shift, bn.alpha)
+                    cur = r
+                else:
+                    a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
+                    ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
+                    cur = a
         self._saved[pre] = saved
 
     def _ru_bwd(self, ru, dout, dx=None, extra=None):
@@ -675,7 +700,8 @@ class UNetEngine:
                 self._bn_bwd(bn, g, r, dr)
             else:
                 dr = g
-            self._wgrad(conv, xin, dr, need_bias=bn is None and conv is not self._top_bias_conv)
+            self._wgrad(conv, xin, dr, need_bias=bn is None and conv is not self._top_bias_conv,
+                        in_tf=sv.get(f"tf{i}"))
             if i > 0:
                 da = self._buf(f"{pre}.da{i - 1}", xin.shape)
                 self._dgrad(conv, dr, da)
@@ -759,14 +785,25 @@ class UNetEngine:
             ru_fwd(lvl["bottom"], down_out, sub_out)
         up, ubn = lvl["upconv"], lvl["upbn"]
         oshape = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], lvl["outc"])
-        au = self._buf(f"{p}au.{tag}", oshape)
         if train:
             u = self._buf(f"{p}u", oshape)
             self._conv_train(up, cat, u, ubn)
-            ops.bn_act_fwd(u, au, ubn.scale, ubn.shift, ubn.alpha, dropout=ubn.drop())
-            self._saved[p + "up"] = {"cat": cat, "u": u, "au": au}
-            self._ru_fwd_train(lvl["upru"], au, out)
+            upru = lvl["upru"]
+            conv0, bn0 = upru["units"][0]
+            if (bn0 is None and upru["res"] is None and conv0.cin == conv0.cout == lvl["outc"]
+                    and self._tf_ok(u, out, conv0)):
+                # conv-only unit with an identity residual (the top of the net): its conv, the weight
+                # gradient and the in-kernel residual are the only readers of act(bn(u)) -- they
+                # apply it themselves, the normalised tensor is never written
+                self._saved[p + "up"] = {"cat": cat, "u": u}
+                self._ru_fwd_train(upru, u, out, in_tf=(ubn.scale, ubn.shift, ubn.alpha))
+            else:
+                au = self._buf(f"{p}au.t", oshape)
+                ops.bn_act_fwd(u, au, ubn.scale, ubn.shift, ubn.alpha, dropout=ubn.drop())
+                self._saved[p + "up"] = {"cat": cat, "u": u}
+                self._ru_fwd_train(upru, au, out)
         else:
+            au = self._buf(f"{p}au.e", oshape)
             sc, sh = ubn.eval_affine()
             pack, wsrc, bias = up.folded(sc, sh)
             ops.convT3d_fwd(cat, au, pack, wsrc, bias, prelu_alpha=ubn.alpha)
@@ -775,9 +812,9 @@ class UNetEngine:
     def _level_bwd(self, lvl, dout, dx=None, extra=None):
         p = lvl["prefix"]
         sv = self._saved[p + "up"]
-        cat, u, au = sv["cat"], sv["u"], sv["au"]
+        cat, u = sv["cat"], sv["u"]
         c = lvl["c"]
-        dau = self._buf(f"{p}dau", au.shape)
+        dau = self._buf(f"{p}dau", u.shape)
         self._ru_bwd(lvl["upru"], dout, dx=dau)
         du = self._buf(f"{p}du", u.shape)
         self._bn_bwd(lvl["upbn"], dau, u, du)
@@ -931,6 +968,9 @@ class UNetEngine:
     # residual-branch overlap on a second side stream: measured neutral on MI355X (the branch
     # convs are short and the join sits on the critical path), so it is off by default
     overlap_branches = False
+    # BatchNorm-apply + PReLU folded into the consumer conv's staging where the kernels allow it
+    # (segmi_in_affine); SEGMI_FUSE_BN=0 keeps the separate pass for A/B measurements
+    fuse_bn_apply = os.environ.get("SEGMI_FUSE_BN", "1") != "0"
     _side2 = None
 
     def _fork_branch(self):

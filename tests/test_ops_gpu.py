@@ -133,6 +133,50 @@ def test_conv3d_fwd_pair_equals_two_convs(dtype, cin, cout, stride, sp):
     assert not ops.conv3d_pair_ok(big, big.clone(), big.clone())
 
 
+@pytest.mark.parametrize("c,cout,with_alpha,mode", [(16, 16, True, "identity"), (16, 16, False, "stats"),
+                                                   (32, 32, True, "stats"), (16, 32, True, "plain")])
+def test_conv3d_input_transform_equals_separate_bn_pass(c, cout, with_alpha, mode):
+    """segmi_in_affine: the consumer conv (forward and weight gradient) applies the producer's
+    BatchNorm-apply + PReLU while staging -- bit-identical to bn_act_fwd followed by the plain calls,
+    zero padding and the identity residual included."""
+    dtype = torch.bfloat16
+    n, sp = 4, (18, 60, 120)          # 256 ragged columns: the ring kernel takes the layer
+    u = to_ndhwc(rnd((n, c) + sp, 401, 2.0), dtype)
+    scale = (1 + 0.3 * rnd((c,), 402)).to(DEV)
+    shift = (0.2 * rnd((c,), 403)).to(DEV)
+    alpha = torch.tensor([0.15], device=DEV) if with_alpha else None
+    w = rnd((cout, c, 3, 3, 3), 404, 0.05).to(DEV)
+    b = (0.1 * rnd((cout,), 405)).to(DEV)
+    packed = ops.wpack(dtype, 0, w, c, cout, 3)
+    au = torch.empty_like(u)
+    ops.bn_act_fwd(u, au, scale, shift, alpha)
+    y_ref = torch.empty((n,) + sp + (cout,), dtype=dtype, device=DEV)
+    y = torch.empty_like(y_ref)
+    assert ops.conv3d_in_affine_ok(u, y, 3, 1)
+    rows = ops.conv3d_stats_rows(u, y, 3, 1)
+    st_ref = torch.zeros((rows, 2, cout), device=DEV) if mode == "stats" else None
+    st = torch.zeros((rows, 2, cout), device=DEV) if mode == "stats" else None
+    tf = (scale, shift, alpha)
+    ops.conv3d_fwd(au, y_ref, packed, None, 0, b, 3, 1, residual=au if mode == "identity" else None, stats=st_ref)
+    ops.conv3d_fwd(u, y, packed, None, 0, b, 3, 1, residual=u if mode == "identity" else None, stats=st, in_tf=tf)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    if st is not None:
+        assert torch.equal(st[:rows - 131], st_ref[:rows - 131])
+    # weight gradient with the transform on X
+    dy = to_ndhwc(rnd((n, cout) + sp, 406), dtype)
+    ws = torch.empty(ops.conv3d_wgrad_workspace(au, dy, 3, 1), dtype=torch.uint8, device=DEV)
+    dw_ref, dw = torch.empty_like(w), torch.empty_like(w)
+    ops.conv3d_wgrad(au, dy, dw_ref, None, 3, 1, ws)
+    torch.cuda.synchronize()
+    ops.conv3d_wgrad(u, dy, dw, None, 3, 1, ws, in_tf=tf)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw_ref)
+    # layers off the ring kernel refuse the transform loudly
+    small = torch.empty((1, 4, 4, 4, 64), dtype=dtype, device=DEV)
+    assert not ops.conv3d_in_affine_ok(small, small.clone(), 3, 1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3d_epilogue_prelu_residual_and_views(dtype):
     """PReLU + residual epilogue, reading from / writing into channel slices (concat by offset)."""
