@@ -177,6 +177,7 @@ class _Conv:
         ver = self.eng.weights_version
         if self.eng._packed_version != ver:
             self.eng._repack_all()
+        self.eng._await_packs()
         hit = self._packs.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -425,6 +426,27 @@ class UNetEngine:
             for (conv, key), buf in zip(slots, batch.packed):
                 conv._packs[key] = (ver, buf)
         self._packed_version = ver
+
+    _pack_ev = None
+
+    def _repack_async(self):
+        """Training forward: the one re-pack launch of the step runs on the side stream while the
+        main stream does the first layer (Cin = 1: no packed operand); the first MFMA conv waits."""
+        if self._packed_version == self.weights_version or not self.overlap_wgrad:
+            return
+        main, side = torch.cuda.current_stream(), self._side_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)                 # after the optimiser step that changed the weights
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self._repack_all()
+            self._pack_ev = torch.cuda.Event()
+            self._pack_ev.record(side)
+
+    def _await_packs(self):
+        if self._pack_ev is not None:
+            torch.cuda.current_stream().wait_event(self._pack_ev)
+            self._pack_ev = None
 
     def param(self, key):
         return self._pviews["model." + key]
@@ -896,6 +918,7 @@ class UNetEngine:
         else:
             logits = self._buf("logits." + ("t" if train else "e"), shape)
         if train:
+            self._repack_async()
             self._saved.clear()
             self._nbt_flat += 1        # every BatchNorm runs exactly once per training forward
             self._drop_step += 1       # fresh dropout masks for this step (shared by its backward)
