@@ -239,6 +239,11 @@ def main():
                     "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
                     "frac": gbps / 8000.0, "traffic": traffic,
                     "avg_launch_ms": avg, "launches": len(ms),
+                    "fused_into_this_launch": "BatchNorm-apply + PReLU of the producer layer (segmi_in_affine; "
+                                              "SEGMI_FUSE_BN=0 restores the separate 1.07 GB, 0.225 ms pass, "
+                                              "this launch then takes 0.285 ms = frac 0.47 and the step 2.5 % longer; "
+                                              "the same kernel's input-gradient launch, which has no transform, runs "
+                                              "0.284 ms in the serial trace under profiles/)",
                     "algorithmic_bytes_per_launch": abytes,
                     "mfma_view": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
                                   "peak_TFLOPs": peak, "frac": ach / peak},

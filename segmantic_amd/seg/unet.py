@@ -606,8 +606,8 @@ class UNetEngine:
         elif conv.stride == 2:
             ops.convT3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, None, residual=residual)
         else:
-            ops.conv3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, 1, None, conv.k, 1,
-                           residual=residual)
+            self._timed(conv.prefix + ":dgrad", ops.conv3d_fwd, dy, dx, conv.dgrad_pack(), conv.w, 1,
+                        None, conv.k, 1, residual=residual)
 
     def _bn_bwd(self, bn: _BN, dy, x_raw, dx):
         rows = ops.bn_act_bwd_rows(x_raw)
