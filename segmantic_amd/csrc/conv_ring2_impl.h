@@ -127,6 +127,18 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
     return bn_prelu_bf16x8(v, sc, sh, in_alpha, in_act);
   };
+  auto transform_act = [&](frag_t v) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
+    return bn_prelu_bf16x8(v, sc, sh, in_alpha, true);
+  };
+  auto transform_lin = [&](frag_t v) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
+    return bn_prelu_bf16x8(v, sc, sh, 0.f, false);
+  };
   if (in_tf) __syncthreads();
   // prologue: planes z0-1 .. z0+4 -> ring slots 0 .. 5
 #pragma unroll
@@ -250,17 +262,24 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     }
     // ---- write the prefetched planes into the free ring slots (zb+6 .. zb+9 mod R)
     if (more) {
+      // three copies of the commit loop behind wave-uniform branches (none / affine / affine +
+      // PReLU) instead of per-element selects on the two runtime flags
+      auto commit = [&](auto tf) {
 #pragma unroll
-      for (int pl = 0; pl < G::TD; ++pl) {
-        const int slot = (zb + 6 + pl) % G::R;
-        const bool zin = z0 + zb + 5 + pl < p.Di;
+        for (int pl = 0; pl < G::TD; ++pl) {
+          const int slot = (zb + 6 + pl) % G::R;
+          const bool zin = z0 + zb + 5 + pl < p.Di;
 #pragma unroll
-        for (int q = 0; q < NLP; ++q) {
-          frag_t val = stg[pl][q];
-          if (in_tf && zin && g_off[q] >= 0) val = transform(val);
-          if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = val;
+          for (int q = 0; q < NLP; ++q) {
+            frag_t val = stg[pl][q];
+            if (zin && g_off[q] >= 0) val = tf(val);       // zero padding stays zero
+            if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = val;
+          }
         }
-      }
+      };
+      if (!in_tf) commit([](frag_t v) { return v; });
+      else if (in_act) commit(transform_act);
+      else commit(transform_lin);
     }
     // every staging register is dead from here on; say so on ALL control-flow paths (touch_v)
 #pragma unroll
