@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
       if (in_tf) xin = inside ? (xin | (1u << k)) : (xin & ~(1u << k));
     }
   };
-  auto commit = [&]() {
+  // (the X loop exists in three copies behind wave-uniform branches: no transform / affine /
+  // affine + PReLU -- no per-element selects on the two runtime flags)
+  auto commit_with = [&](auto tf) {
 #pragma unroll
     for (int k = 0; k < NLY; ++k) {
       const int i = tid + 256 * k;
@@ -203,12 +205,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
       const int i = tid + 256 * k;
       if (i < G::XROWS * G::XCPR) {
         frag_t val = rx[k];
-        if constexpr (sizeof(T) == 2) {
-          if (in_tf && ((xin >> k) & 1u)) val = bn_prelu_bf16x8(val, tsc, tsh, in_alpha, in_act);
-        }
+        if ((xin >> k) & 1u) val = tf(val);
         *reinterpret_cast<frag_t*>(xsm + (i / G::XCPR) * G::XROWB + (i % G::XCPR) * 16) = val;
       }
     }
+  };
+  auto commit = [&]() {
+    if constexpr (sizeof(T) == 2) {
+      if (in_act) { commit_with([&](frag_t v) { return bn_prelu_bf16x8(v, tsc, tsh, in_alpha, true); }); return; }
+      if (in_tf) { commit_with([&](frag_t v) { return bn_prelu_bf16x8(v, tsc, tsh, 0.f, false); }); return; }
+    }
+    commit_with([](frag_t v) { return v; });
   };
   if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
