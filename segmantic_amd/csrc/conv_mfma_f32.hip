@@ -5,8 +5,6 @@
 #include "convt_ps_impl.h"
 namespace segmi {
 int conv_mfma_f32(const ConvParams& p, int ksize, int stride, hipStream_t st) {
-  if (conv_ring_zsplit(SEGMI_F32, p.Cin, ksize, stride, p.N, p.Do, p.Ho, p.Wo) > 0)
-    return launch_conv_ring_t<float>(p, st);
   if (conv_ks_ok(SEGMI_F32, p.Cin, ksize, stride)) return launch_conv_ks_t<float, 16>(p, stride, st);
   return launch_conv_mfma_t<float>(p, ksize, stride, st);
 }
