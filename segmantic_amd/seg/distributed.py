@@ -64,32 +64,36 @@ class GradSync:
         self._hi = self.n
         self._works = []
 
-    def _launch(self, lo: int, hi: int):
+    def _launch(self, lo: int, hi: int, after=()):
         if hi <= lo:
             return
         chunk = self.flat_grad[lo:hi]
         if self._side is not None:
             ev = torch.cuda.Event()
-            ev.record()                      # gradients of the chunk are complete here
+            ev.record()                      # gradients of the chunk are complete here ...
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
+                for e in after:              # ... and once these (other-stream) events are reached
+                    self._side.wait_event(e)
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group,
                                                    async_op=True))
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
 
-    def ready(self, lo: int):
+    def ready(self, lo: int, after=()):
+        """gradients at offsets >= lo are final once the current stream's present point and the
+        events in ``after`` (work of other streams, e.g. the weight-gradient stream) are reached"""
         if self.world == 1:
             return
         while self._hi - lo >= self.bucket_elems:
-            self._launch(self._hi - self.bucket_elems, self._hi)
+            self._launch(self._hi - self.bucket_elems, self._hi, after)
             self._hi -= self.bucket_elems
 
-    def finish(self):
+    def finish(self, after=()):
         if self.world == 1:
             return
-        self._launch(0, self._hi)
+        self._launch(0, self._hi, after)
         self._hi = 0
         for w in self._works:
             w.wait()

@@ -978,7 +978,9 @@ class UNetEngine:
     def timing_ms(self, key: str) -> List[float]:
         return [s.elapsed_time(e) for s, e in self.timings.get(key, [])]
 
-    grad_hook = None  # callable(lo_offset): gradients at arena offsets >= lo are final
+    # callable(lo_offset, events): gradients at arena offsets >= lo are final once the main stream's
+    # current point and `events` (side-stream weight gradients) have been reached
+    grad_hook = None
     # SEGMI_SERIAL=1 keeps every kernel on one stream (per-kernel profiling without co-running work)
     overlap_wgrad = os.environ.get("SEGMI_SERIAL", "0") != "1"
     _side = None
@@ -1019,8 +1021,15 @@ class UNetEngine:
 
     def _grads_ready(self, lo: int):
         if self.grad_hook is not None:
-            self._join_side()     # the hook (bucketed all-reduce) orders itself after the main stream
-            self.grad_hook(lo)
+            # the hook (bucketed all-reduce on its own stream) orders itself after the main stream's
+            # current point AND after the weight-gradient stream -- the main stream itself does not
+            # wait for the weight gradients here (that stall cost the overlap in data-parallel runs)
+            after = []
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                after.append(ev)
+            self.grad_hook(lo, after)
 
     def bump(self):
         """Call after the parameters changed (optimiser step, load_state_dict)."""
