@@ -151,13 +151,23 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTPar
   const int t_begin = blockIdx.x * per_wg;
   const int t_end = t_begin + per_wg < ntiles ? t_begin + per_wg : ntiles;
 
+  // Tile coordinates are carried, not decoded: a workgroup walks consecutive tiles (x fastest), so
+  // the next tile is an increment with three possible wraps instead of three runtime divisions
+  // (SALU divisions are ~20-instruction sequences and every SALU instruction is an issue turn of
+  // the wave: the loop had 452 of them around 27 MFMAs).  (nx*) = tile being fetched, (c*) = tile
+  // being computed.
+  int nx_x, nx_y, nx_z, nx_n;
+  {
+    int t = t_begin;
+    nx_x = t % p.tx; t /= p.tx;
+    nx_y = t % p.ty; t /= p.ty;
+    nx_z = t % p.tz;
+    nx_n = t / p.tz;
+  }
+  int c_x = nx_x, c_y = nx_y, c_z = nx_z, c_n = nx_n;
   frag_t pf[G::NLD];
-  auto fetch = [&](int tile) {
-    int t = tile;
-    const int txi = t % p.tx; t /= p.tx;
-    const int tyi = t % p.ty; t /= p.ty;
-    const int tzi = t % p.tz;
-    const int n = t / p.tz;
+  auto fetch = [&]() {
+    const int txi = nx_x, tyi = nx_y, tzi = nx_z, n = nx_n;
     const int iz0 = tzi * 2, iy0 = tyi * 2, ix0 = txi * 16;
     const char* tile_in = (const char*)p.in +
         ((((int64_t)n * p.Di + iz0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * (int64_t)G::ES;
@@ -171,16 +181,29 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTPar
       pf[k] = frag_t{0u, 0u, 0u, 0u};
       if (ok) pf[k] = *reinterpret_cast<const frag_t*>(tile_in + s_goff[k]);
     }
+    // advance to the tile after this one
+    if (++nx_x == p.tx) {
+      nx_x = 0;
+      if (++nx_y == p.ty) {
+        nx_y = 0;
+        if (++nx_z == p.tz) { nx_z = 0; ++nx_n; }
+      }
+    }
   };
 
-  if (t_begin < t_end) fetch(t_begin);
+  // element strides of one output row / plane (loop invariant)
+  const int64_t o_dy = (int64_t)p.Wo * p.ldo, o_dz = (int64_t)p.Ho * o_dy;
+  const int64_t r_dy = (int64_t)p.Wo * p.ldr, r_dz = (int64_t)p.Ho * r_dy;
+  if (t_begin < t_end) fetch();
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();   // weights staged (first pass) / previous tile's fragments consumed
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k)
       if (s_h[k] >= 0) *reinterpret_cast<frag_t*>(il + s_loff[k]) = pf[k];
     __syncthreads();
-    if (tile + 1 < t_end) fetch(tile + 1);   // in flight under the MFMAs and the stores below
+    const int txi = c_x, tyi = c_y, tzi = c_z, n = c_n;    // the tile now in LDS
+    c_x = nx_x; c_y = nx_y; c_z = nx_z; c_n = nx_n;
+    if (tile + 1 < t_end) fetch();   // in flight under the MFMAs and the stores below
 
     f32x4 acc[8][NT];
 #pragma unroll
@@ -211,11 +234,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTPar
     }
 
     // ---- epilogue: bias, statistics, PReLU, x-parity exchange, residual, store
-    int t = tile;
-    const int txi = t % p.tx; t /= p.tx;
-    const int tyi = t % p.ty; t /= p.ty;
-    const int tzi = t % p.tz;
-    const int n = t / p.tz;
     const int iz = tzi * 2 + wz, iy = tyi * 2 + wy, ix = txi * 16 + r;
     const int ox_pre0 = 2 * ix, ox_st = 2 * ix + (g & 1);
     T* outp = (T*)p.out;
@@ -223,14 +241,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTPar
     // per-lane 32-bit element offsets inside an output row; the row base is wave-uniform
     const int lo_out = ox_st * p.ldo + 8 * (g >> 1);
     const int lo_res = ox_st * p.ldr + 8 * (g >> 1);
+    // one 64-bit row index per tile; the other three rows are +1 row / +1 plane
+    const int64_t row00 = (((int64_t)n * p.Do + 2 * iz) * p.Ho + 2 * iy) * p.Wo;
+    T* const orow00 = outp + row00 * p.ldo;
+    const T* const rrow00 = resp ? resp + row00 * p.ldr : nullptr;
 #pragma unroll
     for (int dh2 = 0; dh2 < 4; ++dh2) {
       const int rd = dh2 >> 1, rh = dh2 & 1;
       const int oz = 2 * iz + rd, oy = 2 * iy + rh;
       const bool zy_ok = oz < p.Do && oy < p.Ho;   // wave-uniform
-      const int64_t row = (((int64_t)n * p.Do + oz) * p.Ho + oy) * p.Wo;
-      T* orow = outp + row * p.ldo;
-      const T* rrow = resp ? resp + row * p.ldr : nullptr;
+      T* orow = orow00 + (rd ? o_dz : 0) + (rh ? o_dy : 0);
+      const T* rrow = rrow00 ? rrow00 + (rd ? r_dz : 0) + (rh ? r_dy : 0) : nullptr;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4 v0 = acc[rd * 4 + rh * 2 + 0][j] + bias4[j];
