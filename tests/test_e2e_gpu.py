@@ -513,3 +513,30 @@ def test_dropout_training_step_matches_oracle_with_the_same_masks():
     torch.cuda.synchronize()
     y2 = eng._bufs["logits.t"][..., :16].float().cpu().permute(0, 4, 1, 2, 3)
     assert float((y2 - y).abs().max()) > 1e-2 * float(y.abs().max())
+
+
+def test_fused_bn_apply_training_step_is_bit_identical_to_the_separate_pass():
+    """segmi_in_affine in the engine: with the BatchNorm-apply folded into the consumer conv / weight
+    gradient (top of the decoder, first-level unit) a bf16 training step gives the very same
+    logits, loss, gradients and post-Adam weights as with the separate bn_act_fwd pass."""
+    ref = deterministic_fill_(RefUNet(3, 1, 16, (16, 32, 64), (2, 2)), 0)
+    sd = {"_model." + k: v.clone() for k, v in ref.state_dict().items()}
+    img, lab = synthetic_batch(4, 64, 16, seed=31)       # 64^3: the ring kernel takes the 16-channel layers
+    results = []
+    for fuse in (True, False):
+        net = Net(num_classes=16, num_channels=1, channels=(16, 32, 64), strides=(2, 2))
+        net.load_state_dict(sd)
+        net.to(DEV).train()
+        net.mixed_precision = True
+        eng = net._engine_for()
+        eng.fuse_bn_apply = fuse
+        res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+        torch.cuda.synchronize()
+        fused_layers = sum(1 for sv in eng._saved.values() for k, v in sv.items()
+                           if k.startswith("tf") and v is not None)
+        results.append((eng._bufs["logits.t"].clone(), float(res["loss"].cpu()), eng.flat_grad.clone(),
+                        eng.flat.clone(), fused_layers))
+    (la, lossa, ga, wa, na), (lb, lossb, gb, wb, nb) = results
+    assert na >= 1 and nb == 0            # the fused run really took the fused path
+    assert torch.equal(la, lb) and lossa == lossb
+    assert torch.equal(ga, gb) and torch.equal(wa, wb)
