@@ -111,6 +111,17 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
  * Replaces the two torch.nn.Conv3d of monai ResidualUnit, monai_unet.py:114-124. */
 int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
                          const segmi_act* out_b);
+/* The same pairing for MFMA layers (the stride-2 first subunit + residual convolution of the deeper
+ * ResidualUnits, inference): ONE convolution whose fragment pack holds both weight sets
+ * (segmi_wpack of the concatenated [2c][cin][27] weight, per-channel scale = folded BatchNorm for the
+ * first c outputs, 1 for the rest) writes 2c channels, PReLU only on the first `act_channels`:
+ *   out[..., :act_channels] = prelu(conv_a(in) + bias[:c]) ; out[..., act_channels:] = conv_b(in) + bias[c:]
+ * Consumers read the two halves as channel-slice views (ld = 2c).  Same bits as the two calls. */
+int segmi_conv3d_split_act_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                              int stride);
+int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* out,
+                               const void* packed, const float* bias, const float* prelu_alpha,
+                               int act_channels, int ksize, int stride, void* stream);
 int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
                           const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
                           const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,

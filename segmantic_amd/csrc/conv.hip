@@ -176,6 +176,40 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
                         stride, (hipStream_t)stream, out_b, w_b, bias_b);
 }
 
+int segmi_conv3d_split_act_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                              int stride) {
+  if (!act_ok(in) || !act_ok(out) || (dtype != SEGMI_F32 && dtype != SEGMI_BF16)) return 0;
+  // the tile kernel must take the layer (it is the one that honours act_tiles): k3 stride 2 MFMA
+  return mfma_ok(in->c, out->c) && ksize == 3 && stride == 2 && !conv_ks_ok(dtype, in->c, ksize, stride) &&
+         !conv_ring_ok(dtype, in->c, ksize, stride, out);
+}
+
+int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
+                               const float* bias, const float* prelu_alpha, int act_channels, int ksize,
+                               int stride, void* stream) {
+  SEGMI_CHECK_ARG(segmi_conv3d_split_act_ok(dtype, in, out, ksize, stride),
+                  "conv3d_fwd_split_act: layer not eligible (ask segmi_conv3d_split_act_ok)");
+  SEGMI_CHECK_ARG(packed && act_channels > 0 && act_channels % 16 == 0 && act_channels <= out->c,
+                  "conv3d_fwd_split_act: act_channels must be a multiple of 16 within the output channels");
+  SEGMI_CHECK_ARG(in->n == out->n && out->d == out_extent(in->d, ksize, stride) &&
+                      out->h == out_extent(in->h, ksize, stride) && out->w == out_extent(in->w, ksize, stride),
+                  "conv3d_fwd_split_act: output extent does not match the input");
+  const int es = dtype_size(dtype);
+  SEGMI_CHECK_ARG(in->ld % (16 / es) == 0 && out->ld % 4 == 0 && ((uintptr_t)in->data % 16) == 0 &&
+                      ((uintptr_t)out->data % (4 * es)) == 0,
+                  "conv3d_fwd_split_act: MFMA path needs 16-byte aligned input rows");
+  ConvParams p{};
+  p.in = in->data; p.out = out->data; p.wfrag = packed; p.bias = bias; p.alpha = prelu_alpha;
+  p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w;
+  p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
+  p.Cin = in->c; p.Cout = out->c; p.ldi = in->ld; p.ldo = out->ld;
+  p.nchunks = in->c / pick_ck(dtype, in->c);
+  p.ntiles_total = out->c / 16;
+  p.act_tiles = act_channels / 16;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st) : conv_mfma_bf16(p, ksize, stride, st);
+}
+
 int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                               int stride) {
   if (!act_ok(in) || !act_ok(out) || dtype != SEGMI_BF16 || !mfma_ok(in->c, out->c)) return 0;

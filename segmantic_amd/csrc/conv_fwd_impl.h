@@ -29,6 +29,10 @@ struct ConvParams {
   const float* in_scale;
   const float* in_shift;
   const float* in_alpha;
+  // PReLU applies to output-channel tiles < act_tiles only (0 = all): segmi_conv3d_fwd_split_act runs
+  // two convolutions of one input as ONE launch with 2c outputs of which the first c are activated.
+  // Honoured by the tile kernel (conv_fwd_mfma_kernel) only.
+  int act_tiles;
   int dbg;   // diagnostics only (SEGMI_RING2_DBG): 1 = no staging loads, 2 = no stores, 4 = no MFMA loop
 };
 
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
           ssum[j] += v;
           ssq[j] += v * v;
         }
-        if (has_alpha) {
+        if (has_alpha && (p.act_tiles == 0 || nt0 + j < p.act_tiles)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
         }

@@ -170,6 +170,19 @@ def conv3d_fwd_pair(x, y_a, w_a, bias_a, y_b, w_b, bias_b, stride, prelu_alpha_a
                                     _ptr(bias_b), stride, _stream()), "conv3d_fwd_pair")
 
 
+def conv3d_split_act_ok(x, y, ksize, stride) -> bool:
+    ax, ay = act(x), act(y)
+    return bool(lib.segmi_conv3d_split_act_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
+
+
+def conv3d_fwd_split_act(x, y, packed, bias, prelu_alpha, act_channels, ksize, stride) -> None:
+    """one conv with two weight sets (concatenated pack): PReLU on the first ``act_channels`` only"""
+    ax, ay = act(x), act(y)
+    check(lib.segmi_conv3d_fwd_split_act(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed), _ptr(bias),
+                                         _ptr(prelu_alpha), act_channels, ksize, stride, _stream()),
+          "conv3d_fwd_split_act")
+
+
 def convT3d_stats_rows(x, y) -> int:
     ax, ay = act(x), act(y)
     return int(lib.segmi_convT3d_stats_rows(dtype_code(x), C.byref(ax), C.byref(ay)))

@@ -549,6 +549,33 @@ class UNetEngine:
                 and not conv.transposed and conv.k == 3 and conv.stride == 1 and conv.mfma
                 and ops.conv3d_in_affine_ok(x, y, 3, 1))
 
+    merge_eval_pairs = os.environ.get("SEGMI_MERGE_PAIRS", "1") != "0"
+
+    def _merged_eval(self, ru, x, oshape):
+        """(pack, bias, buffer) of the merged subunit-0 + residual convolution of a unit (inference,
+        MFMA layers, segmi_conv3d_fwd_split_act), or None.  The pack concatenates the BatchNorm-folded
+        subunit-0 weight and the residual weight along the output channels; cached per weight version."""
+        units, rc = ru["units"], ru["res"]
+        if not self.merge_eval_pairs or rc is None or len(units) < 2 or units[0][1] is None:
+            return None
+        c0, bn0 = units[0]
+        if not (c0.mfma and rc.mfma and c0.k == 3 and rc.k == 3 and c0.stride == rc.stride
+                and c0.cout == rc.cout and c0.cin == rc.cin and not c0.transposed):
+            return None
+        m = self._buf(f"{ru['prefix']}.merged", oshape + (2 * c0.cout,))
+        if not ops.conv3d_split_act_ok(x, m, 3, c0.stride):
+            return None
+        hit = ru.get("_merged")
+        if hit is None or hit[0] != self.weights_version:
+            sc, sh = bn0.eval_affine()
+            w_cat = torch.cat([c0.w, rc.w], 0).contiguous()
+            scale = torch.cat([sc, torch.ones_like(sc)])
+            bias = torch.cat([torch.addcmul(sh, c0.b, sc), rc.b]).contiguous()
+            pack = ops.wpack(self.dtype, 0, w_cat, c0.cin, 2 * c0.cout, 3, scale=scale)
+            hit = (self.weights_version, pack, bias)
+            ru["_merged"] = hit
+        return hit[1], hit[2], m
+
     def _conv_train(self, conv: _Conv, x, y, bn: Optional[_BN], in_tf=None):
         """raw conv (+bias) with fused statistics, then finalize into bn.*"""
         stats = None
@@ -753,10 +780,12 @@ class UNetEngine:
         n, d, h, w = self._down_shape(x.shape, ru["stride"])
         br = None
         paired = False
+        merged = None
         if ru["res"] is not None:
             rc = ru["res"]
             paired = self._pair_ok(ru, x, out, f"{pre}.ea0", (n, d, h, w))
-            if not paired:
+            merged = None if paired else self._merged_eval(ru, x, (n, d, h, w))
+            if not paired and merged is None:
                 br = self._fork_branch()
                 with torch.cuda.stream(br) if br is not None else _NullCtx():
                     ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
@@ -767,6 +796,13 @@ class UNetEngine:
         nun = len(ru["units"])
         for i, (conv, bn) in enumerate(ru["units"]):
             last = i == nun - 1
+            if i == 0 and merged is not None:
+                # subunit 0 and the residual convolution as ONE launch with 2c outputs (one staging of
+                # x); consumers read the halves as channel-slice views
+                pack, bias, m = merged
+                ops.conv3d_fwd_split_act(x, m, pack, bias, bn.alpha, conv.cout, 3, conv.stride)
+                cur, resid = m[..., :conv.cout], m[..., conv.cout:]
+                continue
             if i == 0 and paired:
                 sc, sh = bn.eval_affine()
                 _, wsrc, bias = conv.folded(sc, sh)

@@ -540,3 +540,23 @@ def test_fused_bn_apply_training_step_is_bit_identical_to_the_separate_pass():
     assert na >= 1 and nb == 0            # the fused run really took the fused path
     assert torch.equal(la, lb) and lossa == lossb
     assert torch.equal(ga, gb) and torch.equal(wa, wb)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_merged_pair_convolutions_in_eval_are_bit_identical(mixed):
+    """Inference: subunit 0 + residual convolution of the deeper units as one split-activation launch
+    (segmi_conv3d_fwd_split_act) gives the very bits of the two separate launches."""
+    _, net = pair(16, (16, 32, 64, 128), (2, 2, 2))
+    net.eval()
+    net.mixed_precision = mixed
+    img, _ = synthetic_batch(2, 64, 4, seed=9)
+    eng = net._engine_for()
+    outs = []
+    with torch.no_grad():
+        for merge in (True, False):
+            eng.merge_eval_pairs = merge
+            outs.append(net(img.to(DEV)).clone())
+    torch.cuda.synchronize()
+    used = sum(1 for k in eng._bufs if k.endswith(".merged"))
+    assert used >= 2, sorted(eng._bufs)
+    assert torch.equal(outs[0], outs[1])
