@@ -234,7 +234,7 @@ def main():
                     # rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)
                     traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
                 out["roofline"] = {
-                    "kernel": "segmi::conv_ring2_kernel<unsigned short, 16, 1, true> -- forward launch of the "
+                    "kernel": "segmi::conv_ring2_kernel<unsigned short, 16, 1, 0> -- forward launch of the "
                               "full-resolution 16->16 k3 conv (identity residual from the LDS ring)",
                     "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
                     "frac": gbps / 8000.0, "traffic": traffic,

@@ -32,9 +32,12 @@
 
 namespace segmi {
 
-// PLAIN: no PReLU and no statistics (the two full-resolution launches of a training step and every
-// input-gradient launch): the epilogue is bias + residual + convert only
-template <typename T, int CK, int NT, bool PLAIN>
+// MODE: bit 0 = PReLU, bit 1 = BatchNorm statistics -- compile-time, because every epilogue
+// instruction is an issue turn of the wave.  0 ("PLAIN": the two full-resolution launches of a
+// training step and every input-gradient launch) is bias + residual + convert only, 1 the
+// inference layers (folded BatchNorm + PReLU), 2 the training forward of a conv in front of a
+// BatchNorm, 3 both.
+template <typename T, int CK, int NT, int MODE>
 __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvParams p) {
   static_assert(sizeof(T) == 2, "bf16 only");
   using G = RingGeom<T, CK>;
@@ -163,10 +166,11 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     if (p.bias) bias4[jt] = *reinterpret_cast<const f32x4*>(p.bias + (nt0 + jt) * 16 + 4 * g);
     touch_v(bias4[jt]);
   }
-  const bool has_alpha = !PLAIN && p.alpha != nullptr;
+  constexpr bool PLAIN = MODE == 0;
+  constexpr bool has_alpha = (MODE & 1) != 0;
   float alpha = has_alpha ? *p.alpha : 0.f;
   touch_s(alpha);
-  const bool want_stats = !PLAIN && p.stats != nullptr;
+  constexpr bool want_stats = (MODE & 2) != 0;
   f32x4 ssum[NT], ssq[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) { ssum[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   }
 }
 
-template <typename T, int CK, int NT, bool PLAIN>
+template <typename T, int CK, int NT, int MODE>
 static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   using G = RingGeom<T, CK>;
   constexpr int dt = SEGMI_BF16;
@@ -392,7 +396,7 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
                       (int64_t)p.Ho * p.Wo * (p.ldr > 0 ? p.ldr : 1) < (1ll << 31),
                   "conv3d: plane too large for the ring kernel's 32-bit offsets");
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
-  auto kern = conv_ring2_kernel<T, CK, NT, PLAIN>;
+  auto kern = conv_ring2_kernel<T, CK, NT, MODE>;
   static bool attr_done = false;
   if (!attr_done && G::LDS_BYTES + 2 * CK * 4 > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -406,8 +410,12 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
 
 template <typename T, int CK, int NT>
 static int launch_conv_ring2_cfg(const ConvParams& p, hipStream_t st) {
-  if (!p.alpha && !p.stats) return launch_conv_ring2_k<T, CK, NT, true>(p, st);
-  return launch_conv_ring2_k<T, CK, NT, false>(p, st);
+  switch ((p.alpha ? 1 : 0) | (p.stats ? 2 : 0)) {
+    case 0: return launch_conv_ring2_k<T, CK, NT, 0>(p, st);
+    case 1: return launch_conv_ring2_k<T, CK, NT, 1>(p, st);
+    case 2: return launch_conv_ring2_k<T, CK, NT, 2>(p, st);
+    default: return launch_conv_ring2_k<T, CK, NT, 3>(p, st);
+  }
 }
 
 // bf16 ring layers: 16 -> 16*m and 32 -> 32*m
