@@ -144,6 +144,24 @@ __device__ __forceinline__ frag_t bn_prelu_bf16x8(const frag_t raw, const float 
   return o;
 }
 
+// The same transform for 0 <= alpha <= 1 (every PReLU in practice, ReLU, LeakyReLU): there
+// z > 0 ? z : alpha*z == max(z, alpha*z) bit for bit (signed zeros and NaN included), which is a
+// packed multiply and one max per element instead of multiply + compare + select.  Callers pick it
+// behind a wave-uniform branch.
+__device__ __forceinline__ frag_t bn_prelu01_bf16x8(const frag_t raw, const float (&sc)[8], const float (&sh)[8],
+                                                    const float alpha) {
+  frag_t o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_cv x = {__uint_as_float(raw[q] << 16), __uint_as_float(raw[q] & 0xffff0000u)};
+    const f32x2_cv s = {sc[2 * q], sc[2 * q + 1]}, h = {sh[2 * q], sh[2 * q + 1]};
+    const f32x2_cv z = __builtin_elementwise_fma(x, s, h);       // one rounding per element, as fmaf
+    const f32x2_cv az = z * alpha;
+    o[q] = pack_bf16x2(fmaxf(z[0], az[0]), fmaxf(z[1], az[1]));
+  }
+  return o;
+}
+
 // sum over the 16 lanes that share (lane>>4): result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
   v += __shfl_xor(v, 1);

@@ -136,6 +136,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
     return bn_prelu_bf16x8(v, sc, sh, in_alpha, true);
   };
+  auto transform_act01 = [&](frag_t v) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
+    return bn_prelu01_bf16x8(v, sc, sh, in_alpha);
+  };
+  const bool in_act01 = in_act && in_alpha >= 0.f && in_alpha <= 1.f;
   auto transform_lin = [&](frag_t v) {
     float sc[8], sh[8];
 #pragma unroll
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
         }
       };
       if (!in_tf) commit([](frag_t v) { return v; });
+      else if (in_act01) commit(transform_act01);
       else if (in_act) commit(transform_act);
       else commit(transform_lin);
     }

@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
   };
   auto commit = [&]() {
     if constexpr (sizeof(T) == 2) {
+      if (in_act && in_alpha >= 0.f && in_alpha <= 1.f) {
+        commit_with([&](frag_t v) { return bn_prelu01_bf16x8(v, tsc, tsh, in_alpha); });
+        return;
+      }
       if (in_act) { commit_with([&](frag_t v) { return bn_prelu_bf16x8(v, tsc, tsh, in_alpha, true); }); return; }
       if (in_tf) { commit_with([&](frag_t v) { return bn_prelu_bf16x8(v, tsc, tsh, 0.f, false); }); return; }
     }

@@ -133,8 +133,9 @@ def test_conv3d_fwd_pair_equals_two_convs(dtype, cin, cout, stride, sp):
     assert not ops.conv3d_pair_ok(big, big.clone(), big.clone())
 
 
-@pytest.mark.parametrize("c,cout,with_alpha,mode", [(16, 16, True, "identity"), (16, 16, False, "stats"),
-                                                   (32, 32, True, "stats"), (16, 32, True, "plain")])
+@pytest.mark.parametrize("c,cout,with_alpha,mode", [(16, 16, 0.15, "identity"), (16, 16, None, "stats"),
+                                                   (32, 32, 0.15, "stats"), (16, 32, 1.5, "plain"),
+                                                   (16, 16, 0.0, "plain")])
 def test_conv3d_input_transform_equals_separate_bn_pass(c, cout, with_alpha, mode):
     """segmi_in_affine: the consumer conv (forward and weight gradient) applies the producer's
     BatchNorm-apply + PReLU while staging -- bit-identical to bn_act_fwd followed by the plain calls,
@@ -144,7 +145,8 @@ def test_conv3d_input_transform_equals_separate_bn_pass(c, cout, with_alpha, mod
     u = to_ndhwc(rnd((n, c) + sp, 401, 2.0), dtype)
     scale = (1 + 0.3 * rnd((c,), 402)).to(DEV)
     shift = (0.2 * rnd((c,), 403)).to(DEV)
-    alpha = torch.tensor([0.15], device=DEV) if with_alpha else None
+    # slopes in [0, 1] take the max() form of the transform, others the compare / select form
+    alpha = torch.tensor([with_alpha], device=DEV) if with_alpha is not None else None
     w = rnd((cout, c, 3, 3, 3), 404, 0.05).to(DEV)
     b = (0.1 * rnd((cout,), 405)).to(DEV)
     packed = ops.wpack(dtype, 0, w, c, cout, 3)
