@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     // software pipeline over the (plane, k-step) iterations, fragments PD iterations ahead (an
     // iteration is 2 - 6 MFMAs = 32 - 96 clk against >= 128 clk of loaded LDS latency; the depth is
     // what the variant's register budget allows)
-    constexpr int PD = CK == 16 ? (PLAIN ? 4 : 3) : (NT == 1 ? 4 : 2);
+    constexpr int PD = CK == 16 ? (MODE == 3 ? 3 : 4) : (NT == 1 ? 4 : 2);
     frag_t a[PD + 1][2];
     auto issue = [&](int it, frag_t (&dst)[2]) {
       const int c = it / J, j = it % J;
