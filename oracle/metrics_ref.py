@@ -39,8 +39,28 @@ def ref_dice_metric(pred_label: torch.Tensor, true_label: torch.Tensor, num_clas
     d0 = torch.where(not_nan, d, torch.zeros_like(d))
     per_b = d0.sum(1) / not_nan.sum(1).clamp(min=1)
     valid_b = not_nan.sum(1) > 0
-    mean = per_b[valid_b].mean() if valid_b.any() else torch.tensor(float("nan"))
+    # MONAI do_metric_reduction: where no batch item has a valid class the result is 0, not NaN
+    mean = per_b[valid_b].mean() if valid_b.any() else torch.tensor(0.0)
     return d, mean
+
+
+def ref_confusion_metrics(pred_label: torch.Tensor, true_label: torch.Tensor, num_classes: int):
+    """``ConfusionMatrixMetric(metric_name=["sensitivity", "specificity", "precision", "accuracy"])``
+    as the reference builds it (``monai_unet.py:645-646``; MONAI defaults include_background=True,
+    compute_sample=False, reduction="mean"): per (batch item, class) tp / fp / tn / fn of the
+    one-hot volumes, averaged over batch and classes FIRST, then
+    sensitivity = tp/(tp+fn), specificity = tn/(tn+fp), precision = tp/(tp+fp),
+    accuracy = (tp+tn)/(tp+fp+tn+fn).  pred/true [B,1,*sp] integer labels -> 4 floats."""
+    p = F.one_hot(pred_label[:, 0].long(), num_classes).movedim(-1, 1).double()
+    t = F.one_hot(true_label[:, 0].long(), num_classes).movedim(-1, 1).double()
+    ax = list(range(2, p.dim()))
+    tp = (p * t).sum(ax)
+    fp = (p * (1 - t)).sum(ax)
+    fn = ((1 - p) * t).sum(ax)
+    tn = ((1 - p) * (1 - t)).sum(ax)
+    tp, fp, tn, fn = (float(v.mean()) for v in (tp, fp, tn, fn))
+    div = lambda a, b: a / b if b != 0 else float("nan")
+    return (div(tp, tp + fn), div(tn, tn + fp), div(tp, tp + fp), div(tp + tn, tp + fp + tn + fn))
 
 
 def ref_normalize(x: np.ndarray) -> np.ndarray:

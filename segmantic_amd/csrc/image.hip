@@ -30,14 +30,19 @@ __global__ void resample_kernel(ResampleParams p) {
     const int ox = e % p.dx;
     const int oy = (e / p.dx) % p.dy;
     const int oz = e / ((int64_t)p.dx * p.dy);
-    const double cx = p.m[0] * ox + p.m[1] * oy + p.m[2] * oz + p.m[3];
-    const double cy = p.m[4] * ox + p.m[5] * oy + p.m[6] * oz + p.m[7];
-    const double cz = p.m[8] * ox + p.m[9] * oy + p.m[10] * oz + p.m[11];
+    double cx = p.m[0] * ox + p.m[1] * oy + p.m[2] * oz + p.m[3];
+    double cy = p.m[4] * ox + p.m[5] * oy + p.m[6] * oz + p.m[7];
+    double cz = p.m[8] * ox + p.m[9] * oy + p.m[10] * oz + p.m[11];
+    if (p.interp & 2) {  // border padding (MONAI Spacing / grid_sample "border"): clamp the coordinate
+      cx = cx < 0.0 ? 0.0 : (cx > p.sx - 1.0 ? p.sx - 1.0 : cx);
+      cy = cy < 0.0 ? 0.0 : (cy > p.sy - 1.0 ? p.sy - 1.0 : cy);
+      cz = cz < 0.0 ? 0.0 : (cz > p.sz - 1.0 ? p.sz - 1.0 : cz);
+    }
     double val = p.defval;
     const bool inside = cx >= -0.5 && cx < p.sx - 0.5 && cy >= -0.5 && cy < p.sy - 0.5 &&
                         cz >= -0.5 && cz < p.sz - 0.5;
     if (inside) {
-      if (p.interp == 1) {
+      if (p.interp & 1) {
         int ix = (int)floor(cx + 0.5), iy = (int)floor(cy + 0.5), iz = (int)floor(cz + 0.5);
         ix = ix < 0 ? 0 : (ix > p.sx - 1 ? p.sx - 1 : ix);
         iy = iy < 0 ? 0 : (iy > p.sy - 1 ? p.sy - 1 : iy);
@@ -129,7 +134,7 @@ int segmi_resample3d(int pixel, const void* src, int sx, int sy, int sz, void* d
                      double default_value, void* stream) {
   SEGMI_CHECK_ARG(src && dst && index_map_host, "resample3d: null pointer");
   SEGMI_CHECK_ARG(sx > 0 && sy > 0 && sz > 0 && dx > 0 && dy > 0 && dz > 0, "resample3d: empty image");
-  SEGMI_CHECK_ARG(interp == 0 || interp == 1, "resample3d: interp must be 0 (linear) or 1 (nearest)");
+  SEGMI_CHECK_ARG(interp >= 0 && interp <= 3, "resample3d: interp must be 0 (linear) or 1 (nearest), +2 for border padding");
   ResampleParams p{};
   p.src = src; p.dst = dst; p.sx = sx; p.sy = sy; p.sz = sz; p.dx = dx; p.dy = dy; p.dz = dz;
   for (int i = 0; i < 12; ++i) p.m[i] = index_map_host[i];

@@ -419,8 +419,10 @@ def label_counts(pred, truth, k, counts) -> None:
 _PIXEL = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.int32: 3, torch.uint16: 4}
 
 
-def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, default=0.0):
-    """src [z,y,x] -> dst [z,y,x]; index_map: 3x4 out-index(x,y,z,1) -> in-index(x,y,z)."""
+def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, default=0.0, border=False):
+    """src [z,y,x] -> dst [z,y,x]; index_map: 3x4 out-index(x,y,z,1) -> in-index(x,y,z).
+    ``border``: clamp the continuous index to the buffer (MONAI ``padding_mode="border"``) instead
+    of ITK's default-pixel-outside rule."""
     _require_device(src)
     if src.dim() != 3 or not src.is_contiguous():
         raise ValueError("resample3d expects a contiguous [z,y,x] tensor")
@@ -429,7 +431,7 @@ def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, defaul
     m = np.ascontiguousarray(np.asarray(index_map, dtype=np.float64).reshape(12))
     sz, sy, sx = src.shape
     check(lib.segmi_resample3d(_PIXEL[src.dtype], _ptr(src), sx, sy, sz, _ptr(dst), dx, dy, dz,
-                               m.ctypes.data_as(C.c_void_p), 1 if nearest else 0,
+                               m.ctypes.data_as(C.c_void_p), (1 if nearest else 0) | (2 if border else 0),
                                float(default), _stream()), "resample3d")
     return dst
 

@@ -138,7 +138,52 @@ class DiceMetric:
         nn_ = ~torch.isnan(d)
         per_b = torch.where(nn_, d, torch.zeros_like(d)).sum(1) / nn_.sum(1).clamp(min=1)
         valid = nn_.sum(1) > 0
-        return per_b[valid].mean() if bool(valid.any()) else torch.tensor(float("nan"))
+        # MONAI do_metric_reduction("mean"): 0 (not NaN) when no item has a valid class
+        return per_b[valid].mean() if bool(valid.any()) else torch.zeros((), device=d.device)
+
+    def reset(self):
+        self._items = []
+
+
+class ConfusionMatrixMetric:
+    """MONAI ``ConfusionMatrixMetric(metric_name=[...])`` as configured at reference
+    ``monai_unet.py:645-646`` (include_background=True, compute_sample=False, reduction="mean"):
+    tp / fp / tn / fn per (volume, class) from the same ``segmi_label_counts`` pass the Dice metric
+    uses, averaged over all accumulated (volume, class) items, then the ratios."""
+
+    NAMES = ("sensitivity", "specificity", "precision", "accuracy")
+
+    def __init__(self, num_classes: int, metric_name=NAMES):
+        unknown = [m for m in metric_name if m not in self.NAMES]
+        if unknown:
+            raise NotImplementedError(f"confusion metrics implemented: {self.NAMES}, not {unknown}")
+        self.k, self.metric_name = num_classes, list(metric_name)
+        self._items = []
+
+    def __call__(self, pred_labels: torch.Tensor, true_labels: torch.Tensor) -> torch.Tensor:
+        """integer label volumes [N, ...] -> [N, K, 4] (tp, fp, tn, fn) float64."""
+        out = []
+        for b in range(pred_labels.shape[0]):
+            p = pred_labels[b].reshape(-1).to(torch.int32).contiguous()
+            t = true_labels[b].reshape(-1).to(device=p.device, dtype=torch.int32).contiguous()
+            counts = torch.empty((self.k, 3), dtype=torch.int64, device=p.device)
+            ops.label_counts(p, t, self.k, counts)
+            c = counts.double()
+            tp, fp, fn = c[:, 0], c[:, 1] - c[:, 0], c[:, 2] - c[:, 0]
+            tn = float(p.numel()) - tp - fp - fn
+            out.append(torch.stack([tp, fp, tn, fn], 1))
+        res = torch.stack(out)
+        self._items.append(res)
+        return res
+
+    def aggregate(self):
+        """-> one 0-d tensor per metric name (MONAI returns a list in ``metric_name`` order)."""
+        if not self._items:
+            return [torch.tensor(float("nan")) for _ in self.metric_name]
+        tp, fp, tn, fn = torch.cat(self._items).mean((0, 1)).unbind()
+        vals = {"sensitivity": tp / (tp + fn), "specificity": tn / (tn + fp),
+                "precision": tp / (tp + fp), "accuracy": (tp + tn) / (tp + fp + tn + fn)}
+        return [vals[m].float() for m in self.metric_name]
 
     def reset(self):
         self._items = []

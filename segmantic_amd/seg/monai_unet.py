@@ -22,7 +22,8 @@ from .. import ops
 from ..image.labels import load_decathlon_tissuelist, load_tissue_list
 from .distributed import GradSync, broadcast_buffers, env_world, init_distributed
 from .inferers import SlidingWindowInferer, sliding_window_inference
-from .losses import DiceLoss, DiceMetric, as_ndhwc, dice_backward, dice_forward
+from .losses import (ConfusionMatrixMetric, DiceLoss, DiceMetric, as_ndhwc, dice_backward,
+                     dice_forward)
 from .optim import make_optimizer, make_scheduler
 from .unet import UNetEngine, UNetParams
 from .utils import make_device
@@ -240,8 +241,10 @@ class Net(torch.nn.Module):
         self.validation_step_outputs.append(out)
         return out
 
-    def on_validation_epoch_end(self):
-        """reference ``:365-397``"""
+    def on_validation_epoch_end(self, sync=None):
+        """reference ``:365-397``.  ``sync(val_dice, val_loss) -> (val_dice, val_loss)``: data-parallel
+        runs pass a broadcast from rank 0 here, so that the LR scheduler, ``best_val_dice`` and the
+        caller's early-stop / checkpoint logic see the same numbers on every rank."""
         val_loss, num_items = 0.0, 0
         for o in self.validation_step_outputs:
             val_loss += float(o["val_loss"].sum().item())
@@ -250,6 +253,8 @@ class Net(torch.nn.Module):
         self.dice_metric.reset()
         mean_val_loss = val_loss / max(num_items, 1)
         self.validation_step_outputs.clear()
+        if sync is not None:
+            mean_val_dice, mean_val_loss = sync(mean_val_dice, mean_val_loss)
         sched = self.lr_schedulers()
         sched.step(mean_val_loss)
         if mean_val_dice > self.best_val_dice:
@@ -279,14 +284,19 @@ class Net(torch.nn.Module):
             sd = {"_model." + k: v for k, v in ckpt.items()}
             hp = {}
         else:
-            sd, hp = ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {}))
+            # a Lightning checkpoint of the reference's Net may carry entries besides the network
+            # (loss / metric buffers such as ``loss_function.class_weight``): only ``_model.*`` is ours
+            sd = {k: v for k, v in ckpt["state_dict"].items() if k.startswith("_model.")}
+            hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
         if "num_classes" not in hp:
             last = [k for k in sd if k.endswith("2.1.conv.unit0.conv.bias") and k.count("submodule") == 0]
             hp["num_classes"] = int(sd[last[0]].shape[0])
         if "num_channels" not in hp:
             hp["num_channels"] = int(sd["_model.model.0.conv.unit0.conv.weight"].shape[1])
-        net = cls(**hp)
+        import inspect
+        known = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        net = cls(**{k: v for k, v in hp.items() if k in known})
         net.load_state_dict(sd, strict=True)
         return net
 
@@ -381,15 +391,20 @@ def train(
     net.cache_rate = cache_rate
     net.mixed_precision = bool(mixed_precision)
 
-    output_dir = Path(output_dir)
-    output_dir.mkdir(exist_ok=True, parents=True)
-    (output_dir / "Dataset.json").write_text(net.dataset.dump_dataset())
-
     if not torch.cuda.is_available():
         raise RuntimeError(
             "segmantic_amd.train needs an MI355X: torch.cuda.is_available() is False and there "
             "is no CPU execution path (the reference's gpu_ids=[] CPU mode is served by the "
             "reference itself)")
+    output_dir = Path(output_dir)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    rank, _, world = env_world()
+    if world > 1:                         # one process per GPU: every rank trains on rank 0's split
+        from .trainer import sync_dataset
+        init_distributed()
+        net.dataset = sync_dataset(net.dataset)
+    if rank == 0:
+        (output_dir / "Dataset.json").write_text(net.dataset.dump_dataset())
     fit(net, output_dir=output_dir, max_epochs=max_epochs, early_stop_patience=early_stop_patience,
         gpu_ids=gpu_ids, ckpt_name=_ckpt_name)
     print(f"train completed, best_metric: {net.best_val_dice:.4f} at epoch {net.best_val_epoch}")
@@ -409,7 +424,11 @@ def predict(
     gpu_ids: List[int] = [],
 ) -> None:
     """reference ``:551-725``: load checkpoint, sliding-window inference per volume, invert the
-    pre-processing on the logits, argmax, save, Dice / confusion statistics when labels exist."""
+    pre-processing on the logits, argmax, save; with labels: per-volume / total Dice tables and the
+    ``ConfusionMatrixMetric`` table (sensitivity, specificity, precision, accuracy).  Not
+    reproduced: the per-volume ``*_confusion.png`` plots (matplotlib; out of scope).
+    The class-Dice tables are headed by the K-1 foreground tissue names (the reference prints all K
+    names over the K-1 foreground values, one column off)."""
     from .pipeline import PredictPipeline
 
     model_file = Path(model_file)
@@ -454,6 +473,8 @@ def predict(
         output_dir = Path(output_dir)
     inferer = SlidingWindowInferer(roi_size=net.spatial_size, sw_batch_size=4, device=device)
     dice_metric = DiceMetric(num_classes, include_background=False)
+    confusion_metrics = ["sensitivity", "specificity", "precision", "accuracy"]
+    conf_matrix = ConfusionMatrixMetric(num_classes, confusion_metrics)
 
     tissue_names = [f"{i}" for i in range(num_classes)]
     if tissue_dict:
@@ -479,6 +500,7 @@ def predict(
             if use_labels:
                 pred_lab = _argmax_labels(val_pred)
                 d = dice_metric(pred_lab, item["label"][None].long())
+                conf_matrix(pred_lab, item["label"][None].long())
                 dn = d.cpu().numpy()
                 print("Mean Dice: ", np.nanmean(dn))
                 print("Class Dice:")
@@ -491,9 +513,11 @@ def predict(
         if world > 1:
             import torch.distributed as dist
             parts = [None] * world
-            dist.all_gather_object(parts, (all_mean_dice, class_dice_sum, class_dice_cnt))
+            conf_local = torch.cat(conf_matrix._items).cpu() if conf_matrix._items else None
+            dist.all_gather_object(parts, (all_mean_dice, class_dice_sum, class_dice_cnt, conf_local))
             if rank != 0:
                 return
+            conf_matrix._items = [p[3] for p in parts if p[3] is not None]
             all_mean_dice = [v for p in parts for v in p[0]]
             sums = [p[1] for p in parts if p[1] is not None]
             class_dice_sum = sum(sums) if sums else None
@@ -510,6 +534,8 @@ def predict(
             print("Total Mean Dice: ", total)
             print("Total Class Dice:")
             print_table(tissue_names[1:], class_dice_sum / np.maximum(class_dice_cnt, 1))
+            print("Total Conf. Matrix Metrics:")
+            print_table(confusion_metrics, (float(x) for x in conf_matrix.aggregate()))
 
 
 def _argmax_labels(logits: torch.Tensor) -> torch.Tensor:

@@ -24,25 +24,25 @@ from ..data.nifti import read_nifti, write_nifti
 
 # ---------------------------------------------------------------------------- orientation
 def io_orientation(affine: np.ndarray) -> np.ndarray:
-    """For each voxel axis: (closest world axis, sign) -- the axis-aligned part of an affine."""
-    R = np.asarray(affine, np.float64)[:3, :3]
-    R = R / np.maximum(np.sqrt((R ** 2).sum(0)), 1e-12)
+    """(closest world axis, sign) per voxel axis, by the rule MONAI's ``Orientation`` takes from
+    nibabel (``io_orientation``): the shear-free part of the direction matrix (polar factor of the
+    unit-column matrix), then for voxel axis 0, 1, 2 in turn the world axis with the largest
+    |component| among those not taken yet."""
+    rzs = np.asarray(affine, np.float64)[:3, :3]
+    norms = np.sqrt((rzs * rzs).sum(0))
+    norms[norms == 0] = 1.0
+    u, sv, vt = np.linalg.svd(rzs / norms, full_matrices=False)
+    keep = sv > sv.max() * 3 * np.finfo(np.float64).eps
+    rot = u[:, keep] @ vt[keep]
     ornt = np.zeros((3, 2), dtype=np.int64)
-    used_w, used_v = set(), set()
-    for _ in range(3):
-        best = None
-        for v in range(3):
-            if v in used_v:
-                continue
-            for w in range(3):
-                if w in used_w:
-                    continue
-                if best is None or abs(R[w, v]) > best[0]:
-                    best = (abs(R[w, v]), v, w)
-        _, v, w = best
-        ornt[v] = (w, 1 if R[w, v] >= 0 else -1)
-        used_v.add(v)
-        used_w.add(w)
+    free = np.ones(3, dtype=bool)
+    for v in range(3):
+        col = np.where(free, np.abs(rot[:, v]), -1.0)
+        w = int(np.argmax(col))
+        if col[w] <= 1e-8 * max(1.0, float(np.abs(rot).max())):
+            raise ValueError("degenerate affine: a voxel axis has no world direction")
+        ornt[v] = (w, -1 if rot[w, v] < 0 else 1)
+        free[w] = False
     return ornt
 
 
@@ -78,24 +78,61 @@ def _affine_spacing(A: np.ndarray) -> np.ndarray:
     return np.sqrt((np.asarray(A, np.float64)[:3, :3] ** 2).sum(0))
 
 
-def spacing_resample(vol: torch.Tensor, affine: np.ndarray, pixdim: Sequence[float],
-                     out_shape: Optional[Sequence[int]] = None):
-    """MONAI ``Spacing`` geometry: out_shape = round((n - 1) * in_sp / out_sp + 1), voxel i_out
-    sits at continuous input index i_out * out_sp / in_sp; trilinear, edge replicate.
+def spacing_geometry(affine: np.ndarray, shape: Sequence[int], pixdim: Sequence[float]):
+    """Output grid of MONAI ``Spacing(pixdim)`` (``diagonal=False``, ``scale_extent=False``) for an
+    input grid (affine, shape): (new affine, new shape).
+
+    The zooms of the direction matrix are replaced by ``pixdim`` while its rotation is kept (the
+    upper-triangular Cholesky factor Z of M^T M carries zooms and shear: M = R Z, new M = R
+    diag(sign(Z_ii) pixdim)); the new extent is the bounding box of the 8 old corner voxels in new
+    index space, ``round(ptp + 1)`` voxels; the new origin is the corner that is minimal there."""
+    A = np.asarray(affine, np.float64)
+    in_sp = _affine_spacing(A)
+    pix = [float(v) for v in pixdim][:3]
+    out_sp = np.asarray(pix + list(in_sp[len(pix):]), np.float64)
+    out_sp[out_sp == 0] = 1.0
+    M = A[:3, :3]
+    Z = np.linalg.cholesky(M.T @ M).T
+    new = np.eye(4)
+    new[:3, :3] = (M @ np.linalg.inv(Z)) @ np.diag(np.sign(np.diag(Z)) * np.abs(out_sp))
+    n = np.asarray(shape, np.float64)
+    corners = np.array([[i * (n[0] - 1), j * (n[1] - 1), k * (n[2] - 1), 1.0]
+                        for i in (0, 1) for j in (0, 1) for k in (0, 1)]).T
+    idx_new = np.linalg.solve(new, A @ corners)[:3]
+    new_shape = [int(v) for v in np.round(idx_new.max(1) - idx_new.min(1) + 1.0)]
+    first = None
+    for c in range(8):
+        if np.allclose((idx_new - idx_new[:, c:c + 1]).min(1), 0.0, rtol=1e-3):
+            first = c
+            break
+    if first is None:
+        raise ValueError("Spacing: affine with a shear that leaves no minimal corner")
+    new[:3, 3] = (A @ corners)[:3, first]
+    return new, new_shape
+
+
+def affine_resample(vol: torch.Tensor, src_affine: np.ndarray, dst_affine: np.ndarray,
+                    dst_shape: Sequence[int]) -> torch.Tensor:
+    """MONAI ``SpatialResample`` (bilinear, border padding): destination voxel i reads the source
+    at continuous index ``inv(src_affine) @ dst_affine @ i`` (the ``align_corners`` flag cancels
+    between MONAI's index normalisation and ``grid_sample``, see ``oracle/pipeline_ref.py``).
     vol [C, x, y, z] float32 on device."""
-    in_sp = _affine_spacing(affine)
-    out_sp = np.asarray(list(pixdim) + [1.0] * 3, np.float64)[:3]
-    n = np.asarray(vol.shape[1:], np.float64)
-    if out_shape is None:
-        out_shape = [int(v) for v in np.round((n - 1) * in_sp / out_sp + 1.0)]
-    m = np.zeros((3, 4))
+    X = np.linalg.solve(np.asarray(src_affine, np.float64), np.asarray(dst_affine, np.float64))
     # kernel arrays are [z][y][x] = our dims (d0, d1, d2) -> kernel x = d2, y = d1, z = d0
-    ratios = out_sp / in_sp
-    m[0, 0], m[1, 1], m[2, 2] = ratios[2], ratios[1], ratios[0]
-    outs = [ops.resample3d(vol[c].contiguous(), out_shape, m, nearest=False) for c in range(vol.shape[0])]
-    A = np.array(affine, np.float64)
-    A[:3, :3] = A[:3, :3] @ np.diag(ratios)
-    return torch.stack(outs), A
+    m = np.zeros((3, 4))
+    for r in range(3):
+        for c in range(3):
+            m[r, c] = X[2 - r, 2 - c]
+        m[r, 3] = X[2 - r, 3]
+    outs = [ops.resample3d(vol[c].contiguous(), list(dst_shape), m, nearest=False, border=True)
+            for c in range(vol.shape[0])]
+    return torch.stack(outs)
+
+
+def spacing_resample(vol: torch.Tensor, affine: np.ndarray, pixdim: Sequence[float]):
+    """``Spacingd(pixdim)`` forward (reference ``monai_unet.py:173-174``): (volume, new affine)."""
+    new_affine, new_shape = spacing_geometry(affine, vol.shape[1:], pixdim)
+    return affine_resample(vol, affine, new_affine, new_shape), new_affine
 
 
 # ---------------------------------------------------------------------------- pipeline
@@ -160,9 +197,8 @@ class PredictPipeline:
         source image's voxel grid."""
         lg = logits.float().contiguous()
         if self.spacing:
-            # inverse Spacing: back to the cropped grid
-            inv_pix = _affine_spacing(item["affine_crop"])
-            lg, _ = spacing_resample(lg, item["affine"], inv_pix, out_shape=item["shape_crop"])
+            # inverse Spacing (Spacing.inverse = the same resample with the two grids swapped)
+            lg = affine_resample(lg, item["affine"], item["affine_crop"], item["shape_crop"])
         lo, hi, full = item["crop"]
         K = lg.shape[0]
         out = torch.zeros((K,) + tuple(full), dtype=torch.float32, device=lg.device)

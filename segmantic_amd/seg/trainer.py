@@ -16,7 +16,7 @@ import math
 import os
 import time
 from pathlib import Path
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -28,24 +28,54 @@ from .pipeline import PredictPipeline
 
 
 class CachedVolumes:
-    """Pre-processed volumes resident in HBM + per-class voxel index lists for crop sampling."""
+    """Pre-processed volumes resident in HBM + per-class voxel index lists for crop sampling.
+
+    The index lists of a volume are one device tensor (classes concatenated) with host-side
+    offsets / counts, so that drawing ``num_samples`` centres is one small gather on a dedicated
+    sampler stream + one pinned D2H copy: the training stream is never synchronised by the
+    sampler (a ``.cpu()`` on the training stream would drain the whole step pipeline)."""
 
     def __init__(self, files, device, num_classes: int):
         pipe = PredictPipeline(device=device, spacing=(), with_label=True)
         self.items = []
+        self.device = torch.device(device)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._pinned = torch.empty(4096, dtype=torch.int64).pin_memory()
         for f in files:
             it = pipe.load(f["image"], f["label"])
             lab = it["label"][0]
             flat = lab.reshape(-1).long()
-            idx = [torch.nonzero(flat == c).reshape(-1).to(torch.int32) for c in range(num_classes)]
-            self.items.append({"image": it["image"], "label": it["label"], "class_idx": idx})
+            idx = [torch.nonzero(flat == c).reshape(-1) for c in range(num_classes)]
+            counts = np.array([int(t.numel()) for t in idx], dtype=np.int64)
+            offsets = np.concatenate([[0], np.cumsum(counts)[:-1]])
+            self.items.append({"image": it["image"], "label": it["label"],
+                               "class_all": torch.cat(idx) if idx else flat[:0],
+                               "class_counts": counts, "class_offsets": offsets,
+                               # NDHWC view of the image the crop kernels read (made once)
+                               "image_ndhwc": it["image"].permute(1, 2, 3, 0).contiguous()[None],
+                               "label_dhw": it["label"][0].contiguous()})
+        torch.cuda.current_stream(self.device).synchronize()   # the cache is complete and static
 
     def __len__(self):
         return len(self.items)
 
+    def lookup(self, item: Dict, positions: np.ndarray) -> np.ndarray:
+        """flat voxel indices ``class_all[positions]`` -> host, without touching the training
+        stream (the index lists never change after construction)."""
+        n = len(positions)
+        with torch.cuda.stream(self._stream):
+            pos = torch.from_numpy(np.ascontiguousarray(positions, dtype=np.int64)).to(
+                self.device, non_blocking=True)
+            got = item["class_all"].index_select(0, pos)
+            self._pinned[:n].copy_(got, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        ev.synchronize()
+        return self._pinned[:n].numpy().copy()
+
 
 def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, num_classes: int,
-                 spatial: Optional[np.ndarray] = None):
+                 spatial: Optional[np.ndarray] = None, cache: Optional[CachedVolumes] = None):
     """MONAI ``generate_label_classes_crop_centers`` + ``correct_crop_centers`` with
     ratios = [0, 1, 1, ...] (background never chosen as a centre, monai_unet.py:201).
 
@@ -54,7 +84,7 @@ def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, 
     have drawn it from the resampled label."""
     shape = list(item["label"].shape[1:])
     ratios = np.array([0.0 if c == 0 else 1.0 for c in range(num_classes)])
-    counts = np.array([int(t.numel()) for t in item["class_idx"]])
+    counts = np.asarray(item["class_counts"])
     ratios = np.where(counts > 0, ratios, 0.0)
     if ratios.sum() == 0:
         ratios = (counts > 0).astype(np.float64)
@@ -64,7 +94,11 @@ def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, 
         c = int(rng.choice(num_classes, p=probs))
         picks.append(c)
         pos.append(int(rng.randint(counts[c])))
-    flat = torch.stack([item["class_idx"][c][p] for c, p in zip(picks, pos)]).cpu().numpy()
+    where = np.array([item["class_offsets"][c] + p for c, p in zip(picks, pos)], dtype=np.int64)
+    if cache is not None:
+        flat = cache.lookup(item, where)
+    else:
+        flat = item["class_all"][torch.from_numpy(where).to(item["class_all"].device)].cpu().numpy()
     centers = np.stack(np.unravel_index(flat, shape), 1)
     if spatial is not None:
         centers = np.stack([np.rint(forward_point(spatial, c)).astype(np.int64) for c in centers])
@@ -94,17 +128,17 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
     for vid in vol_ids:
         it = cache.items[vid]
         spatial = draw_spatial(rng, it["label"].shape[1:]) if net.augment_spatial else None
-        starts = crop_centers(rng, it, roi, net.num_samples, net.num_classes, spatial)
+        starts = crop_centers(rng, it, roi, net.num_samples, net.num_classes, spatial, cache)
         C = it["image"].shape[0]
-        src = it["image"].permute(1, 2, 3, 0).contiguous()[None]            # NDHWC, n = 1
+        src = it["image_ndhwc"]                                              # NDHWC, n = 1
         out_i = torch.empty((len(starts), roi[0], roi[1], roi[2], C), dtype=torch.float32, device=dev)
         out_l = torch.empty((len(starts), roi[0], roi[1], roi[2]), dtype=torch.float32, device=dev)
         flips = [(int(rng.rand() < 0.2)) | (int(rng.rand() < 0.2) << 1) | (int(rng.rand() < 0.2) << 2)
                  for _ in starts]
         if spatial is None:
-            ops.crop_patches(src, it["label"][0].contiguous(), [[0] + s for s in starts], flips, out_i, out_l)
+            ops.crop_patches(src, it["label_dhw"], [[0] + s for s in starts], flips, out_i, out_l)
         else:
-            ops.warp_crop_patches(src, it["label"][0].contiguous(), [[0] + s for s in starts], flips,
+            ops.warp_crop_patches(src, it["label_dhw"], [[0] + s for s in starts], flips,
                                   to_index_map_xyz(spatial), out_i, out_l)
         if net.augment_intensity:
             con, hist, bias, gibbs, spike = draw_intensity(rng, len(starts), roi)
@@ -113,6 +147,108 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
         imgs.append(out_i.permute(0, 4, 1, 2, 3))
         labs.append(out_l.unsqueeze(1))
     return {"image": torch.cat(imgs).contiguous(), "label": torch.cat(labs).contiguous()}
+
+
+def epoch_shard(n: int, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
+    """Volume indices of ``rank`` for ``epoch`` -- torch ``DistributedSampler`` (what Lightning
+    injects for the reference's train loader, ``monai_unet.py:278-286,529-538``): ONE permutation
+    per epoch drawn from a rank-independent seed, padded by wrapping to ``ceil(n / world) * world``
+    entries, dealt ``rank::world``.  Every rank gets the same number of volumes, hence runs the
+    same number of ``training_step`` s (= the same number of gradient all-reduces)."""
+    order = np.random.RandomState((seed + epoch) % (2 ** 32)).permutation(n)
+    if world <= 1:
+        return order
+    per_rank = -(-n // world)
+    total = per_rank * world
+    if total > n:
+        reps = -(-total // n)
+        order = np.concatenate([order] * reps)[:total]
+    return order[rank:total:world]
+
+
+def sync_from_rank0(values: Sequence[float], device) -> List[float]:
+    """Every rank continues with rank 0's numbers (validation metrics -> LR schedule, early stop,
+    checkpoint names): replicas must never take different control-flow decisions."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                     device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.broadcast(t, src=0)
+    return [float(v) for v in t.cpu()]
+
+
+def sync_dataset(dataset):
+    """All ranks use rank 0's train / validation / test file lists (``PairedDataSet`` shuffles with
+    an unseeded RNG, so each process would otherwise draw its own split)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dataset
+    box = [(dataset._train_files, dataset._val_files, dataset._test_files)] if dist.get_rank() == 0 else [None]
+    dist.broadcast_object_list(box, src=0)
+    dataset._train_files, dataset._val_files, dataset._test_files = box[0]
+    return dataset
+
+
+def run_epochs(net, n_train: int, step_fn: Callable, validate_fn: Callable, output_dir: Path,
+               max_epochs: int, early_stop_patience: int, ckpt_name: Callable, batch_volumes: int,
+               seed: int, rank: int, world: int, device=None):
+    """The epoch loop of ``fit``: identical control flow on every rank.
+
+    ``step_fn(volume_ids, rng) -> loss`` (scalar tensor or float) runs one ``training_step``;
+    ``validate_fn() -> {"val_dice", "val_loss"}`` runs the validation epoch (its numbers are
+    already rank 0's, see ``Net.on_validation_epoch_end(sync=...)``)."""
+    rng = np.random.RandomState((seed + 7919 * (rank + 1)) % (2 ** 32))   # crops / flips / augmentation
+    log_dir = Path(output_dir) / "logs"
+    top: List[tuple] = []                         # (val_dice, path), best 3
+    best, bad_epochs = -math.inf, 0
+    log_f = writer = None
+    if rank == 0:
+        log_dir.mkdir(parents=True, exist_ok=True)
+        log_f = open(log_dir / "metrics.csv", "a", newline="")
+        writer = csv.writer(log_f)
+        writer.writerow(["epoch", "train_loss", "val_loss", "val_dice", "lr", "epoch_seconds"])
+    steps_run = 0
+    for epoch in range(max_epochs):
+        net.current_epoch = epoch
+        t0 = time.time()
+        order = epoch_shard(n_train, epoch, seed, rank, world)
+        losses = []
+        for b in range(0, len(order), batch_volumes):
+            losses.append(step_fn(order[b:b + batch_volumes], rng))
+            steps_run += 1
+        if losses and torch.is_tensor(losses[0]):
+            train_loss = float(torch.stack([l.reshape(()) for l in losses]).mean().item())
+        else:
+            train_loss = float(np.mean(losses)) if losses else float("nan")
+        logs = validate_fn()
+        val_dice, val_loss = logs["val_dice"], logs["val_loss"]
+        if rank == 0:
+            path = ckpt_name(output_dir, epoch, val_loss, val_dice)
+            if not math.isnan(val_dice) and (len(top) < 3 or val_dice > min(t[0] for t in top)):
+                net.save_checkpoint(path, epoch=epoch)
+                top.append((val_dice, path))
+                top.sort(key=lambda t: -t[0])
+                for _, p in top[3:]:
+                    if Path(p).exists():
+                        Path(p).unlink()
+                top = top[:3]
+            writer.writerow([epoch, train_loss, val_loss, val_dice, net._opt.lr if net._opt else "",
+                             time.time() - t0])
+            log_f.flush()
+        if not math.isfinite(val_dice):           # EarlyStopping(check_finite=True)
+            print("val_dice is not finite: stopping")
+            break
+        if val_dice > best:
+            best, bad_epochs = val_dice, 0
+        else:
+            bad_epochs += 1
+            if bad_epochs >= early_stop_patience:
+                print(f"early stopping at epoch {epoch} (no val_dice improvement for {bad_epochs} epochs)")
+                break
+    if log_f:
+        log_f.close()
+    return steps_run
 
 
 def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_ids,
@@ -130,6 +266,7 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
     net.train()
     net.configure_optimizers()
     if world > 1:
+        net.dataset = sync_dataset(net.dataset)
         net.enable_grad_sync()
         broadcast_buffers(net)
         import torch.distributed as dist
@@ -138,55 +275,17 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
           f"({len(net.dataset.training_files())} train / {len(net.dataset.validation_files())} val volumes)")
     train_cache = CachedVolumes(net.dataset.training_files(), device, net.num_classes)
     val_cache = CachedVolumes(net.dataset.validation_files(), device, net.num_classes)
-    rng = np.random.RandomState(seed + rank)      # set_determinism(seed=0), reference :229
-    log_dir = Path(output_dir) / "logs"
-    log_dir.mkdir(parents=True, exist_ok=True)
-    top: List[tuple] = []                         # (val_dice, path), best 3
-    best, bad_epochs = -math.inf, 0
-    log_f = open(log_dir / "metrics.csv", "a", newline="") if rank == 0 else None
-    writer = csv.writer(log_f) if log_f else None
-    if writer:
-        writer.writerow(["epoch", "train_loss", "val_loss", "val_dice", "lr", "epoch_seconds"])
-    for epoch in range(max_epochs):
-        net.current_epoch = epoch
-        t0 = time.time()
-        order = rng.permutation(len(train_cache))
-        if world > 1:
-            order = order[rank::world]
-        losses = []
-        for b in range(0, len(order), batch_volumes):
-            batch = make_batch(net, train_cache, order[b:b + batch_volumes], rng)
-            losses.append(net.training_step(batch)["loss"])
-        train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
-        # ---- validation (rank 0 evaluates; every rank keeps the same stopping decision)
+
+    def step_fn(vol_ids, rng):                    # set_determinism(seed=0), reference :229
+        return net.training_step(make_batch(net, train_cache, vol_ids, rng))["loss"]
+
+    def validate_fn():
         if world > 1:
             broadcast_buffers(net)
         for it in val_cache.items:
             net.validation_step({"image": it["image"][None], "label": it["label"][None]})
-        logs = net.on_validation_epoch_end()
-        val_dice, val_loss = logs["val_dice"], logs["val_loss"]
-        if rank == 0:
-            path = ckpt_name(output_dir, epoch, val_loss, val_dice)
-            if not math.isnan(val_dice) and (len(top) < 3 or val_dice > min(t[0] for t in top)):
-                net.save_checkpoint(path, epoch=epoch)
-                top.append((val_dice, path))
-                top.sort(key=lambda t: -t[0])
-                for _, p in top[3:]:
-                    if Path(p).exists():
-                        Path(p).unlink()
-                top = top[:3]
-            writer.writerow([epoch, train_loss, val_loss, val_dice, net._opt.lr, time.time() - t0])
-            log_f.flush()
-        if not math.isfinite(val_dice):           # EarlyStopping(check_finite=True)
-            print("val_dice is not finite: stopping")
-            break
-        if val_dice > best:
-            best, bad_epochs = val_dice, 0
-        else:
-            bad_epochs += 1
-            if bad_epochs >= early_stop_patience:
-                print(f"early stopping at epoch {epoch} (no val_dice improvement for {bad_epochs} epochs)")
-                break
-    if log_f:
-        log_f.close()
+        return net.on_validation_epoch_end(sync=lambda *v: sync_from_rank0(v, device))
+
+    run_epochs(net, len(train_cache), step_fn, validate_fn, output_dir, max_epochs,
+               early_stop_patience, ckpt_name, batch_volumes, seed, rank, world, device)
     return net

@@ -560,3 +560,101 @@ def test_merged_pair_convolutions_in_eval_are_bit_identical(mixed):
     used = sum(1 for k in eng._bufs if k.endswith(".merged"))
     assert used >= 2, sorted(eng._bufs)
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE full-size configurations (C3: 512^3 sliding window; C4: 160^3 / K = 32 training on
+# one GPU): size-independent properties, so that the kernels these sizes select (deferred blend
+# of 343 windows over two lanes; ``conv_ring2<32,.>`` one workgroup per CU, ``convt_ps<.,2>``)
+# are part of the driver's GPU record.
+# ------------------------------------------------------------------------------------------
+def test_full_size_c3_512_sliding_window_bf16():
+    from segmantic_amd.seg.inferers import window_starts
+    net = Net(num_classes=16).to(DEV).eval()
+    net.mixed_precision = True
+    net.spatial_size = [128, 128, 128]
+    wins = window_starts((512, 512, 512), (128, 128, 128), 0.5)
+    assert len(wins) == 343 and wins[0] == (0, 0, 0) and wins[-1] == (384, 384, 384)
+    g = torch.Generator().manual_seed(3)
+    # smooth field + noise: neighbouring windows see different content, logits are not constant
+    low = torch.randn((1, 1, 16, 16, 16), generator=g)
+    vol = F.interpolate(low, size=(512, 512, 512), mode="trilinear", align_corners=False)
+    vol = (vol + 0.25 * torch.randn(vol.shape, generator=g)).to(DEV)
+    with torch.no_grad():
+        d = sliding_window_inference(vol, (128, 128, 128), 4, net, 0.5, "constant",
+                                     return_labels=True, blend="deferred", return_logits=False)
+        lab_d, cnt_d = d.labels.clone(), d.count.clone()
+        del d
+        s = sliding_window_inference(vol, (128, 128, 128), 4, net, 0.5, "constant",
+                                     return_labels=True, blend="stream")
+    torch.cuda.synchronize()
+    assert lab_d.shape == (1, 1, 512, 512, 512) and lab_d.dtype == torch.uint8
+    assert bool(torch.isfinite(s.logits).all())
+    # count map of the dense schedule: 1 at the corners, 8 where two windows overlap per axis
+    assert float(cnt_d.min()) == 1.0 and float(cnt_d.max()) == 8.0
+    assert torch.equal(cnt_d, s.count)
+    assert torch.equal(lab_d, s.labels)                      # deferred == streaming, bit for bit
+    assert torch.equal(lab_d[0, 0].long(), torch.argmax(s.logits[0], 0))
+    assert int(lab_d.long().unique().numel()) > 1
+    # one window on its own equals the plain forward of that block (interior overlap excluded)
+    with torch.no_grad():
+        y = net(vol[:, :, :128, :128, :128].contiguous()).float()
+    assert torch.equal(s.logits[0, :, :64, :64, :64], y[0, :, :64, :64, :64])
+
+
+def test_full_size_c4_160_k32_training_step_bf16():
+    net = Net(num_classes=32).to(DEV).train()
+    net.mixed_precision = True
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((2, 1, 160, 160, 160), generator=g).to(DEV)
+    lab = torch.randint(0, 32, (2, 1, 20, 20, 20), generator=g).float()
+    lab = F.interpolate(lab, size=(160, 160, 160), mode="nearest").to(DEV)      # 8^3 blobs
+    eng = net._engine_for(x)
+    eng.timed = {"2.1.conv.unit0.conv:fwd", "2.1.conv.unit0.conv:wgrad", "2.1.conv.unit0.conv:dgrad"}
+    l1 = float(net.training_step({"image": x, "label": lab})["loss"].cpu())
+    logits = eng._bufs["logits.t"]
+    assert tuple(logits.shape) == (2, 160, 160, 160, 32) and logits.dtype == torch.bfloat16
+    assert bool(torch.isfinite(logits.float()).all())
+    assert bool(torch.isfinite(eng.flat_grad).all()) and float(eng.flat_grad.abs().max()) > 0
+    # the 32 -> 32 full-resolution layer takes the ring kernel (its live timing exists)
+    assert len(eng.timing_ms("2.1.conv.unit0.conv:fwd")) == 1
+    top = eng.levels["upru"]["units"][-1][0]
+    assert (top.cin, top.cout) == (32, 32)
+    from segmantic_amd import ops
+    # ... i.e. the z-marching ring kernel <bf16, 32 channels> (this query == conv_ring_ok in conv.hip)
+    assert ops.conv3d_in_affine_ok(logits, logits, 3, 1)
+    for _ in range(4):
+        l2 = float(net.training_step({"image": x, "label": lab})["loss"].cpu())
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1
+    eng.timed = None
+
+
+def test_sliding_window_more_than_64_origins_falls_back_to_streaming():
+    """``segmi_sw_blend`` takes at most 64 origins per dimension (segmi.h); beyond that the driver
+    must take the streaming blend -- for any predictor callable (boundary B4) -- and still equal
+    the oracle."""
+    img = torch.randn((1, 1, 8, 8, 140), generator=torch.Generator().manual_seed(9))
+
+    def predictor(x):                       # K = 2, position independent
+        x = x.float()
+        return torch.cat([x, 0.5 - 2.0 * x], 1)
+
+    with torch.no_grad():
+        o_ref, _, wins = ref_sliding_window_inference(img, (4, 4, 4), 4, predictor, 0.5, "constant")
+        for blend in ("auto", "deferred"):
+            res = sliding_window_inference(img.to(DEV), (4, 4, 4), 4, predictor, 0.5, "constant",
+                                           return_labels=True, blend=blend)
+            torch.cuda.synchronize()
+            assert float((res.logits.cpu() - o_ref).abs().max()) < 1e-6
+            assert torch.equal(res.labels.cpu().long()[:, 0], torch.argmax(o_ref, 1))
+    assert len(wins) == 3 * 3 * 69
+
+
+def test_dice_loss_refuses_more_than_64_classes_loudly():
+    from segmantic_amd.seg.losses import DiceLoss
+    lg = torch.randn((1, 65, 4, 4, 4), device=DEV)
+    lab = torch.zeros((1, 1, 4, 4, 4), device=DEV)
+    with pytest.raises(RuntimeError, match="64 classes"):
+        DiceLoss(to_onehot_y=True, softmax=True)(lg, lab)
+    ok = DiceLoss(to_onehot_y=True, softmax=True)(lg[:, :64].contiguous(), lab)
+    assert bool(torch.isfinite(ok))

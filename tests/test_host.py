@@ -329,3 +329,30 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
                 spilled.append((name, int(cnt)))
     assert seen > 100, seen
     assert not spilled, spilled
+
+
+def test_load_from_checkpoint_accepts_a_lightning_file_with_extra_entries(tmp_path):
+    """A checkpoint written by the reference's Lightning ``Net`` carries more than the network:
+    loss / metric buffers in ``state_dict`` (e.g. ``loss_function.class_weight``), optimizer and
+    callback state, extra hyper-parameters.  Only ``_model.*`` and the constructor kwargs matter
+    (reference ``monai_unet.py:564-574``)."""
+    import torch
+    from segmantic_amd.seg.monai_unet import Net
+    src = Net(num_classes=3, channels=(4, 8), strides=(2,))
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    assert all(k.startswith("_model.") for k in sd)
+    sd["loss_function.class_weight"] = torch.ones(3)
+    sd["dice_metric._buffers"] = torch.zeros(1)
+    ckpt = {"state_dict": sd, "epoch": 12, "global_step": 345,
+            "pytorch-lightning_version": "2.1.0",
+            "hyper_parameters": {"num_classes": 3, "num_channels": 1, "spatial_dims": 3,
+                                 "spatial_size": [32, 32, 32], "channels": (4, 8), "strides": (2,),
+                                 "dropout": 0.0, "act": "PRELU", "some_future_flag": True},
+            "optimizer_states": [{"state": {}, "param_groups": []}],
+            "lr_schedulers": [{}], "callbacks": {"EarlyStopping": {"wait_count": 3}}}
+    path = tmp_path / "epoch=12-val_loss=0.31-val_dice=0.8123.ckpt"
+    torch.save(ckpt, str(path))
+    net = Net.load_from_checkpoint(path)
+    assert net.num_classes == 3 and net.spatial_size == [32, 32, 32]
+    for k, v in src.state_dict().items():
+        assert torch.equal(net.state_dict()[k], v), k

@@ -615,6 +615,54 @@ def test_adam_sgd_match_torch():
     assert float((pd.cpu() - pr.detach()).abs().max()) < 2e-7
 
 
+@pytest.mark.parametrize("decouple", [False, True])
+@pytest.mark.parametrize("eps", [1e-8, 1e-16])
+def test_adabelief_matches_adabelief_pytorch_rule(decouple, eps):
+    """reference monai_unet.py:305-314: AdaBelief(lr, eps, betas=(0.9, 0.999), weight_decouple,
+    fixed_decay=False, rectify=False) -- known-answer test against oracle/optim_ref.py, including
+    the in-place ``exp_avg_var.add_(eps)`` that lets eps accumulate in the stored second moment."""
+    from oracle.optim_ref import RefAdaBelief
+    n = 50021
+    p0, g = rnd((n,), 75).numpy(), rnd((n,), 76, 0.1).numpy()
+    for wd in (0.0, 1e-2):
+        ref = RefAdaBelief(n, lr=1e-3, eps=eps, weight_decay=wd, weight_decouple=decouple)
+        pr = p0.copy()
+        pd = torch.from_numpy(p0).to(DEV)
+        m, s = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for step in range(1, 4):
+            gs = (g * step).astype(np.float32)
+            pr = ref.step(pr, gs)
+            ops.adabelief_step(pd, torch.from_numpy(gs).to(DEV), m, s, 1e-3, 0.9, 0.999, eps, wd,
+                               decouple, step)
+        torch.cuda.synchronize()
+        # f32 update of O(1) parameters: 1 ulp of the parameter + fma-vs-separate rounding
+        assert float(np.abs(pd.cpu().numpy() - pr).max()) < 3e-7, (decouple, eps, wd)
+        assert float(np.abs(m.cpu().numpy() - ref.m).max()) < 1e-7
+        rel = np.abs(s.cpu().numpy() - ref.s) / np.maximum(np.abs(ref.s), 1e-30)
+        assert float(rel.max()) < 1e-5
+        # the stored second moment carries the accumulated eps (3 steps: ~eps*(1+b2+b2^2))
+        assert float(s.min()) >= eps * 2.9
+
+
+def test_flat_adabelief_from_reference_optimizer_dict():
+    """make_optimizer() with the reference's ``optimizer`` dict (monai_unet.py:83-90) drives the
+    same kernel over the arena."""
+    from oracle.optim_ref import RefAdaBelief
+    from segmantic_amd.seg.optim import make_optimizer
+    n = 4099
+    p0, g = rnd((n,), 77).numpy(), rnd((n,), 78, 0.1).numpy()
+    flat, grad = torch.from_numpy(p0).to(DEV), torch.from_numpy(g).to(DEV)
+    opt = make_optimizer({"optimizer": "AdaBelief", "lr": 2e-3, "epsilon": 1e-16,
+                          "weight_decouple": True}, flat, grad)
+    ref = RefAdaBelief(n, lr=2e-3, eps=1e-16, weight_decouple=True)
+    pr = p0.copy()
+    for _ in range(2):
+        pr = ref.step(pr, g)
+        opt.step()
+    torch.cuda.synchronize()
+    assert float(np.abs(flat.cpu().numpy() - pr).max()) < 3e-7
+
+
 def test_argmax_bit_exact_with_ties():
     g = torch.Generator().manual_seed(81)
     for K in (7, 4, 16, 32):     # scalar kernel (7) and the K/4-lanes-per-voxel kernel
@@ -933,3 +981,27 @@ def test_ensemble_kernels_match_monai_semantics():
         ref[labs[model] == tissue] = tissue
     torch.cuda.synchronize()
     assert torch.equal(lo.cpu(), ref)
+
+
+def test_confusion_matrix_metric_and_empty_dice_aggregate_match_monai_rule():
+    """reference monai_unet.py:645-646, 705-725: ConfusionMatrixMetric(sensitivity, specificity,
+    precision, accuracy) -- tp/fp/tn/fn averaged over (volume, class) first, then the ratios."""
+    from oracle.metrics_ref import ref_confusion_metrics, ref_dice_metric
+    from segmantic_amd.seg.losses import ConfusionMatrixMetric, DiceMetric
+    g = torch.Generator().manual_seed(123)
+    K = 5
+    pred = torch.randint(0, K, (3, 1, 9, 10, 11), generator=g)
+    true = torch.randint(0, K - 1, (3, 1, 9, 10, 11), generator=g)      # class 4 absent in truth
+    cm = ConfusionMatrixMetric(K)
+    for b in range(3):                                                  # accumulated over calls
+        cm(pred[b:b + 1].to(DEV), true[b:b + 1].to(DEV))
+    got = [float(v) for v in cm.aggregate()]
+    want = ref_confusion_metrics(pred, true, K)
+    assert np.allclose(got, want, rtol=1e-6, atol=0), (got, want)
+    # Dice metric: all classes absent in the truth -> MONAI's mean reduction yields 0, not NaN
+    dm = DiceMetric(K, include_background=False)
+    zeros = torch.zeros((1, 1, 4, 4, 4), dtype=torch.long)
+    d = dm(pred[:1, :, :4, :4, :4].to(DEV), zeros.to(DEV))
+    assert bool(torch.isnan(d).all())
+    assert float(dm.aggregate()) == 0.0
+    assert float(ref_dice_metric(pred[:1, :, :4, :4, :4], zeros, K)[1]) == 0.0
