@@ -211,18 +211,21 @@ int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labe
                            const float* coef, float grad_scale, const segmi_act* dlogits,
                            float* scratch, float* bias_grad, void* stream);
 
-/* torch.optim.Adam / SGD semantics over one flat f32 arena, monai_unet.py:292-304,346.
- * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+/* torch.optim.Adam / SGD semantics over one flat f32 arena, monai_unet.py:292-304,346, and
+ * adabelief_pytorch.AdaBelief(rectify=False, fixed_decay=False), monai_unet.py:305-314.
+ * Hyper-parameters are doubles, as the Python optimisers hold them: derived scalars (1 - beta,
+ * lr / bias_correction, ...) are formed in double and rounded to f32 once, like torch's scalar
+ * arguments.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
 int segmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                    float* max_exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int64_t step, float grad_scale,
+                    float* max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, int64_t step, float grad_scale,
                     void* stream);
-int segmi_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
-                   float momentum, float weight_decay, int first_step, float grad_scale,
+int segmi_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, double lr,
+                   double momentum, double weight_decay, int first_step, float grad_scale,
                    void* stream);
 int segmi_adabelief_step(float* param, const float* grad, float* exp_avg, float* exp_avg_var,
-                         int64_t n, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int weight_decouple, int64_t step,
+                         int64_t n, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, int weight_decouple, int64_t step,
                          float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- sliding window ------- */

@@ -31,6 +31,7 @@ import numpy as np
 class RefAdaBelief:
     def __init__(self, n: int, lr: float, eps: float = 1e-16, betas=(0.9, 0.999),
                  weight_decay: float = 0.0, weight_decouple: bool = True):
+        self.lr64, self.wd64 = float(lr), float(weight_decay)   # Python doubles, as the optimiser holds them
         self.lr, self.eps, self.betas = np.float32(lr), np.float32(eps), betas
         self.wd, self.decouple = np.float32(weight_decay), bool(weight_decouple)
         self.m = np.zeros(n, np.float32)
@@ -45,7 +46,7 @@ class RefAdaBelief:
         g = g.astype(np.float32).copy()
         b1, b2 = f(self.betas[0]), f(self.betas[1])
         if self.decouple:
-            p = p * f(1.0 - float(self.lr) * float(self.wd))
+            p = p * f(1.0 - self.lr64 * self.wd64)
         elif self.wd != 0:
             g = g + self.wd * p
         self.t += 1
@@ -56,5 +57,5 @@ class RefAdaBelief:
         self.s = self.s * b2 + (r * r) * f(1.0 - self.betas[1])
         self.s = self.s + self.eps                       # in place in adabelief_pytorch
         denom = np.sqrt(self.s) / f(math.sqrt(bc2)) + self.eps
-        step_size = f(float(self.lr) / bc1)
+        step_size = f(self.lr64 / bc1)
         return (p - step_size * (self.m / denom)).astype(np.float32)

@@ -147,10 +147,13 @@ def ref_compute_shape_offset(shape, in_affine, out_affine):
     all_dist = corners_out[:-1].copy()
     corners_out = corners_out[:-1] / corners_out[-1]
     out_shape = np.round(np.ptp(corners_out, axis=1) + 1.0)
+    # "corner is the smallest, shift the corner to origin": the first corner whose distance to every
+    # other corner is non-negative in all dimensions, with MONAI's AFFINE_TOL = 1e-3 taken as an
+    # absolute tolerance in voxels (rotated affines from f32 NIfTI headers are sheared by ~1e-7)
     offset = None
     for i in range(corners_w.shape[1]):
         min_corner = np.min(all_dist - all_dist[:, i:i + 1], 1)
-        if np.allclose(min_corner, 0.0, rtol=1e-3):
+        if np.all(min_corner > -1e-3):
             offset = corners_w[:3, i]
             break
     assert offset is not None

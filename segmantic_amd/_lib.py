@@ -85,9 +85,9 @@ SIGNATURES = {
     "segmi_dice_chunks": (_i, [_AP]),
     "segmi_softmax_dice_fwd": (_i, [_i, _AP, _P, _P, _P, _P, _f, _f, _P]),
     "segmi_softmax_dice_bwd": (_i, [_i, _AP, _P, _P, _f, _AP, _P, _P, _P]),
-    "segmi_adam_step": (_i, [_P, _P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i64, _f, _P]),
-    "segmi_sgd_step": (_i, [_P, _P, _P, _i64, _f, _f, _f, _i, _f, _P]),
-    "segmi_adabelief_step": (_i, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i, _i64, _f, _P]),
+    "segmi_adam_step": (_i, [_P, _P, _P, _P, _P, _i64, _d, _d, _d, _d, _d, _i64, _f, _P]),
+    "segmi_sgd_step": (_i, [_P, _P, _P, _i64, _d, _d, _d, _i, _f, _P]),
+    "segmi_adabelief_step": (_i, [_P, _P, _P, _P, _i64, _d, _d, _d, _d, _d, _i, _i64, _f, _P]),
     "segmi_sw_gather": (_i, [_i, _AP, _i, _P, _i, _i, _AP, _P]),
     "segmi_sw_scatter_add": (_i, [_i, _AP, _P, _i, _P, _AP, _P, _P]),
     "segmi_sw_finalize": (_i, [_AP, _P, _i, _P, _i, _P]),

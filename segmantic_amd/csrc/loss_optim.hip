@@ -215,17 +215,17 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
 // ---------------------------------------------------------------- optimisers
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v,
-                            float* __restrict__ vmax, int64_t n, float beta1, float beta2,
-                            float eps, float wd, float step_size, float bc2_sqrt,
+                            float* __restrict__ vmax, int64_t n, float omb1, float beta2,
+                            float omb2, float eps, float wd, float step_size, float bc2_sqrt,
                             float grad_scale) {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float gi = g[i] * grad_scale;
     const float pi = p[i];
     if (wd != 0.f) gi = fmaf(wd, pi, gi);
     float mi = m[i];
-    mi = mi + (1.f - beta1) * (gi - mi);          // exp_avg.lerp_(grad, 1 - beta1)
+    mi = mi + omb1 * (gi - mi);                   // exp_avg.lerp_(grad, 1 - beta1)
     float vi = v[i] * beta2;
-    vi = fmaf((1.f - beta2) * gi, gi, vi);        // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    vi = fmaf(omb2 * gi, gi, vi);                 // mul_(beta2).addcmul_(g, g, 1 - beta2)
     m[i] = mi;
     v[i] = vi;
     float vv = vi;
@@ -253,19 +253,19 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 __global__ void adabelief_kernel(float* __restrict__ p, const float* __restrict__ g,
                                  float* __restrict__ m, float* __restrict__ s, int64_t n,
-                                 float lr, float beta1, float beta2, float eps, float wd,
-                                 int decouple, float step_size, float bc2_sqrt,
-                                 float grad_scale) {
+                                 float decay, float beta1, float omb1, float beta2,
+                                 float omb2, float eps, float wd, int decouple,
+                                 float step_size, float bc2_sqrt, float grad_scale) {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float gi = g[i] * grad_scale;
     float pi = p[i];
     if (wd != 0.f) {
-      if (decouple) pi *= (1.f - lr * wd);
+      if (decouple) pi *= decay;             // p.mul_(1 - lr * weight_decay)
       else gi = fmaf(wd, pi, gi);
     }
-    const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+    const float mi = fmaf(omb1, gi, m[i] * beta1);     // mul_(beta1).add_(g, alpha=1 - beta1)
     const float r = gi - mi;
-    float si = s[i] * beta2 + (1.f - beta2) * r * r;
+    float si = fmaf(omb2 * r, r, s[i] * beta2);        // mul_(beta2).addcmul_(r, r, value=1 - beta2)
     si += eps;  // exp_avg_var.add_(eps) is in place in adabelief_pytorch
     m[i] = mi;
     s[i] = si;
@@ -374,41 +374,45 @@ int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labe
 }
 
 int segmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                    float* max_exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int64_t step, float grad_scale,
+                    float* max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, int64_t step, float grad_scale,
                     void* stream) {
   SEGMI_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "adam: bad arguments");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, opt_blocks(n), 256, 0, (hipStream_t)stream, param, grad,
-                     exp_avg, exp_avg_sq, max_exp_avg_sq, n, beta1, beta2, eps, weight_decay,
-                     step_size, bc2_sqrt, grad_scale);
+                     exp_avg, exp_avg_sq, max_exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)eps, (float)weight_decay, step_size, bc2_sqrt,
+                     grad_scale);
   SEGMI_LAUNCH_CHECK("adam");
   return SEGMI_OK;
 }
 
-int segmi_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
-                   float momentum, float weight_decay, int first_step, float grad_scale,
+int segmi_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, double lr,
+                   double momentum, double weight_decay, int first_step, float grad_scale,
                    void* stream) {
-  SEGMI_CHECK_ARG(param && grad && n > 0 && (momentum == 0.f || momentum_buf), "sgd: bad arguments");
+  SEGMI_CHECK_ARG(param && grad && n > 0 && (momentum == 0.0 || momentum_buf), "sgd: bad arguments");
   hipLaunchKernelGGL(sgd_kernel, opt_blocks(n), 256, 0, (hipStream_t)stream, param, grad,
-                     momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale);
+                     momentum_buf, n, (float)lr, (float)momentum, (float)weight_decay, first_step,
+                     grad_scale);
   SEGMI_LAUNCH_CHECK("sgd");
   return SEGMI_OK;
 }
 
 int segmi_adabelief_step(float* param, const float* grad, float* exp_avg, float* exp_avg_var,
-                         int64_t n, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int weight_decouple, int64_t step,
+                         int64_t n, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, int weight_decouple, int64_t step,
                          float grad_scale, void* stream) {
   SEGMI_CHECK_ARG(param && grad && exp_avg && exp_avg_var && n > 0 && step > 0, "adabelief: bad arguments");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adabelief_kernel, opt_blocks(n), 256, 0, (hipStream_t)stream, param, grad,
-                     exp_avg, exp_avg_var, n, lr, beta1, beta2, eps, weight_decay,
-                     weight_decouple, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+                     exp_avg, exp_avg_var, n, (float)(1.0 - lr * weight_decay), (float)beta1,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)weight_decay, weight_decouple, (float)(lr / bc1), (float)sqrt(bc2),
+                     grad_scale);
   SEGMI_LAUNCH_CHECK("adabelief");
   return SEGMI_OK;
 }

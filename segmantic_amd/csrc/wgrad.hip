@@ -108,7 +108,7 @@ static inline int wg_direct_blocks(const segmi_act* dy) {
 static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 static inline int wg_slabs(int dtype, const segmi_act* x, const segmi_act* dy, int ksize,
                            int stride) {
-  if (wg_mfma_ok(dtype, x, dy, ksize)) return wgrad_gx(dtype, x, dy, stride);
+  if (wg_mfma_ok(dtype, x, dy, ksize)) return wgrad_gx(dtype, x, dy, ksize, stride);
   if (wg_small_ok(dtype, x, dy, ksize)) return conv_small_wgrad_slabs(dy);
   return wg_direct_blocks(dy);
 }
@@ -166,8 +166,9 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
     p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
     if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
     const int ct = wgrad_ct(dtype, x->c, dy->c);
+    const bool ws = wgrad_ws_gx(dtype, x, dy, ksize, stride) > 0;
     const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, slabs, st)
-                                      : wgrad_mfma_bf16(p, ksize, stride, ct, slabs, st);
+                                      : wgrad_mfma_bf16(p, ksize, stride, ws ? -ct : ct, slabs, st);
     if (rc) return rc;
   } else if (wg_small_ok(dtype, x, dy, ksize)) {
     const int rc = conv_small_wgrad(dtype, x, dy, partials, stride, st);

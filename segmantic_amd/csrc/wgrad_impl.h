@@ -38,6 +38,9 @@ struct WgradParams {
   int N, Dx, Hx, Wx, Dy, Hy, Wy, Cin, Cout, ldx, ldy;
   int tz, ty, tx;
   int ntiles;
+  int zs, zper;   // wave-specialised kernel: z-segments per column, z-tiles per segment
+  unsigned x_bytes, y_bytes;   // ... and the byte extents of the two tensors (buffer num_records)
+  unsigned long long* stamps;  // diag build: s_memtime stamps of workgroup 0, [iter][12 waves][4]
   int ci_chunks;
   int dbg;
   // optional input transform of X (segmi_in_affine): the BatchNorm-apply + PReLU that produced the
@@ -353,7 +356,38 @@ static inline int wgrad_ct(int dtype, int cin, int cout) {
   if (cout % 32 == 0) return 21;
   return 11;
 }
-static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int stride) {
+// ---- wave-specialised kernel (wgrad_ws_impl.h): bf16 k3 layers whose two tile buffers fit one CU
+// and that have enough tiles per workgroup for its pipeline to matter.  Encodes the choice made by
+// the launcher (wgrad_mfma_bf16) so that the workspace query sizes the same number of slabs.
+static inline bool wgrad_ws_cfg_ok(int stride, int ct) {
+  // 16-channel X (the wide, memory-bound layers).  2x2 channel tiles: stride 1 measured 2x slower
+  // than wgrad_mfma_kernel on 32x32 @ 32^3 (latency-bound, 16 tiles per workgroup); stride 2 does
+  // not fit (2 x 103 KB of LDS)
+  (void)stride;
+  return ct == 11 || ct == 21;
+}
+static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride) {
+  static const bool enabled = !(getenv("SEGMI_WGRAD_WS") && atoi(getenv("SEGMI_WGRAD_WS")) == 0);
+  if (!enabled || dtype != SEGMI_BF16 || ksize != 3) return 0;
+  const int ct = wgrad_ct(dtype, x->c, dy->c);
+  if (!wgrad_ws_cfg_ok(stride, ct)) return 0;
+  const int cto = ct / 10, cti = ct % 10;
+  const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
+  int gx = 256 / chunks / 8 * 8;        // one 512-thread workgroup per CU, a multiple of the 8 XCDs
+  if (gx < 8) return 0;
+  // the tile shapes of launch_wgrad_ws (must match)
+  const bool wide = dy->w > 8;
+  int td, th, tw;
+  if (stride == 1) { td = ct == 11 ? 4 : (wide ? 2 : 4); th = 8; tw = wide ? 16 : 8; }
+  else { td = 2; th = wide ? 4 : 8; tw = wide ? 16 : 8; }
+  const int64_t nt = (int64_t)dy->n * cdiv(dy->d, td) * cdiv(dy->h, th) * cdiv(dy->w, tw);
+  // raw buffer loads: 32-bit offsets / num_records over each tensor
+  if (act_voxels(x) * x->ld * 2 >= 0xfff00000ll || act_voxels(dy) * dy->ld * 2 >= 0xfff00000ll) return 0;
+  return nt >= 4 * (int64_t)gx ? gx : 0;
+}
+static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride) {
+  const int ws = wgrad_ws_gx(dtype, x, dy, ksize, stride);
+  if (ws > 0) return ws;
   const int ct = wgrad_ct(dtype, x->c, dy->c);
   const int cto = ct / 10, cti = ct % 10;
   const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));

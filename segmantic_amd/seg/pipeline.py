@@ -100,12 +100,11 @@ def spacing_geometry(affine: np.ndarray, shape: Sequence[int], pixdim: Sequence[
                         for i in (0, 1) for j in (0, 1) for k in (0, 1)]).T
     idx_new = np.linalg.solve(new, A @ corners)[:3]
     new_shape = [int(v) for v in np.round(idx_new.max(1) - idx_new.min(1) + 1.0)]
-    first = None
-    for c in range(8):
-        if np.allclose((idx_new - idx_new[:, c:c + 1]).min(1), 0.0, rtol=1e-3):
-            first = c
-            break
-    if first is None:
+    # the corner that is minimal in every dimension of the new index space, within 1e-3 voxel
+    # (MONAI's AFFINE_TOL; affines read from f32 NIfTI headers carry a 1e-7 shear after rotation)
+    excess = np.array([-(idx_new - idx_new[:, c:c + 1]).min(1).min() for c in range(8)])
+    first = int(np.argmin(excess))
+    if excess[first] > 1e-3:
         raise ValueError("Spacing: affine with a shear that leaves no minimal corner")
     new[:3, 3] = (A @ corners)[:3, first]
     return new, new_shape

@@ -143,6 +143,7 @@ def test_predict_chain_matches_oracle(tmp_path, case):
     assert (lab_ref == 0).any()
 
     # the saved file carries the source grid
+    (tmp_path / "out").mkdir()
     out = pipe.save(torch.from_numpy(lab_gpu).to("cuda:0"), item, tmp_path / "out")
     arr, A_out = read_nifti(out)
     assert arr.shape == shape_zyx and np.allclose(A_out, A_file)
