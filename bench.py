@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native segmantic hot path.
 
-Workload (BASELINE.json configs[1]): one training step of the reference's 3D residual UNet
-(1 input channel, 16 labels, channels 16-32-64-128-256) on a batch of 8 synthetic 128^3 patches
-(the reference's batch: 2 volumes x num_samples 4, monai_unet.py:82,279-285), bf16 storage /
-f32 accumulation: forward -> Dice loss -> backward -> Adam, exactly the order of
+Headline workload (BASELINE.json configs[1]): one training step of the reference's 3D residual
+UNet (1 input channel, 16 labels, channels 16-32-64-128-256) on a batch of 8 synthetic 128^3
+patches (the reference's batch: 2 volumes x num_samples 4, monai_unet.py:82,279-285), bf16
+storage / f32 accumulation: forward -> Dice loss -> backward -> Adam, exactly the order of
 ``training_step`` (monai_unet.py:339-348).  Metric: training voxels per second, whole job.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|infer]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|train|infer|fit]
 
 N > 1 is launched by torchrun (one rank per GPU, RCCL); every rank trains on its own batch (weak
 scaling) with the gradient arena all-reduced in buckets overlapped with backward.
 
-Output: ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     dominant kernel (full-resolution 16->16 conv forward, 49 % of the FLOPs) timed
-               live with HIP events on its launch stream; MFMA-bound nominally, peak 2.5 PFLOP/s
-  cpu_baseline the CPU oracle (torch-CPU restatement of the reference path) timed on the host
-               cores on a bounded sample (N=1, rank 0 only)
+Output: ONE JSON line on rank 0 (contract in the task description).  ``value`` is the training
+throughput; with the default ``--workload all`` on one GPU the same line also carries
+  roofline          dominant kernel of the training step (full-resolution K->K conv forward),
+                    timed live with HIP events on its launch stream, channel counts and kernel
+                    family taken from the engine;
+  cpu_baseline      the CPU oracle (torch-CPU restatement of the reference path) on the host cores,
+                    bounded sample;
+  infer             the second half of BASELINE.json's metric: sliding-window volumes/s for one
+                    512^3 volume (roi 128^3, overlap 0.5) with its own roofline + cpu_baseline;
+  f32_parity_mode   the same training step with f32 storage (``mixed_precision: false``): the
+                    path that meets north_star's 1e-3 logit tolerance (tests/test_unet_gpu.py);
+  fit               sampler + step: training_step fed by the on-GPU patch sampler of the fit loop
+                    (RandCropByLabelClasses + flips from volumes cached in HBM) instead of a fixed batch.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -33,11 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOP_PER_VOXEL_FWD_K16 = 28204.0       # 59.148 GFLOP / 128^3
-FLOP_PER_VOXEL_TRAIN_K16 = 84396.0     # fwd + dgrad + wgrad
-TOP_CONV_FLOP_PER_VOXEL = 2.0 * 27 * 16 * 16   # 16->16 k3 conv at full resolution
-MFMA_PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
-MFMA_PEAK_F32_TFLOPS = 157.3
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X dense (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0
 
 
 def parse():
@@ -45,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "infer"])
+    ap.add_argument("--workload", default="all", choices=["all", "train", "infer", "fit"])
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--classes", type=int, default=16)
@@ -53,6 +59,7 @@ def parse():
     ap.add_argument("--volume", type=int, default=512, help="infer: cubic volume extent")
     ap.add_argument("--overlap", type=float, default=0.5)
     ap.add_argument("--sw-batch", type=int, default=4, help="infer: windows per predictor call")
+    ap.add_argument("--infer-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=128)
     return ap.parse_args()
@@ -85,6 +92,33 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def csrc_hash() -> str:
+    """hash of the kernel sources: stamps offline PMC measurements to the code they were taken on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "segmantic_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (profiles/r02_pmc_traffic.json, written by scripts/make_profiles.py).  PMC counters cannot be
+    read from inside the process; the file is used only if it was measured on these very kernel
+    sources (``source_hash``), otherwise traffic is null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("source_hash") == csrc_hash():
+            return d.get(kernel_key)
+    except Exception:
+        pass
+    return None
+
+
+# --------------------------------------------------------------------------------------------- CPU
 def cpu_baseline_train(size, classes, steps=3):
     """The CPU oracle (port of the reference path) on this host's cores, bounded sample."""
     from oracle.unet_ref import RefUNet, deterministic_fill_, ref_train_step, synthetic_batch
@@ -121,25 +155,189 @@ def cpu_baseline_infer(classes, vol=256, roi=128, overlap=0.5):
             "sample": f"one {vol}^3 volume, roi {roi}^3, overlap {overlap}, scaled by voxel count to 512^3"}
 
 
+# --------------------------------------------------------------------------------------------- GPU
+def top_conv(eng):
+    """the full-resolution conv that produces the logits (MONAI key model.2.1.conv.unit0.conv)"""
+    return eng.levels["upru"]["units"][-1][0]
+
+
+def roofline_of_top_conv(eng, key, voxels, precision, x_like, full_only=False):
+    """HBM roofline of the launch timed under `key`.  Algorithmic bytes: Cin channels in + Cout
+    out per voxel (an identity residual IS the input tensor and is taken from
+    the LDS ring, not a second stream); intensity 54*Cin*Cout/((Cin+Cout)*es) FLOP/B is below the
+    chip ridge (~310 FLOP/B) for the 16- and 32-channel layers, so HBM is the roof."""
+    from segmantic_amd import ops
+    ms = eng.timing_ms(key)
+    if not ms:
+        return None
+    if full_only:       # drop the ragged last window group of a volume: it moves fewer bytes
+        med = statistics.median(ms)
+        ms = [m for m in ms if m > 0.6 * med]
+    conv = top_conv(eng)
+    es = 2 if precision == "bf16" else 4
+    avg = statistics.mean(ms)
+    abytes = voxels * (conv.cin + conv.cout) * es
+    flops = voxels * 2.0 * 27 * conv.cin * conv.cout
+    gbps = abytes / (avg * 1e-3) / 1e9
+    ach = flops / (avg * 1e-3) / 1e12
+    name = ops.conv3d_fwd_kernel_name(x_like, x_like, conv.k, conv.stride) if conv.cin == conv.cout else "?"
+    return {"kernel": f"segmi::{name} -- MONAI layer model.{conv.prefix}: {conv.cin}->{conv.cout} k{conv.k} conv at "
+                      f"full resolution, forward launch (identity residual from the LDS ring)",
+            "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+            "avg_launch_ms": avg, "launches": len(ms), "algorithmic_bytes_per_launch": abytes,
+            "mfma_view": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
+                          "peak_TFLOPs": MFMA_PEAK_TFLOPS[precision], "frac": ach / MFMA_PEAK_TFLOPS[precision]}}
+
+
+def unet_conv_flops_per_voxel(channels, strides, cin, K, train: bool) -> float:
+    """2*MAC of every conv of MONAI UNet(num_res_units=2) per input voxel (28,204 for
+    the default net at K=16); training = fwd + dgrad + wgrad minus the dgrad of the two convs that
+    read the network input (84,396 at K=16)."""
+    def level(inc, outc, chs, sts, vox):
+        c, s = chs[0], sts[0]
+        v = vox / (s ** 3)
+        down = 27 * inc * c + 27 * c * c + (27 if s != 1 else 1) * inc * c * (1 if (s != 1 or inc != c) else 0)
+        total = 2.0 * v * down
+        if len(chs) > 2:
+            total += level(c, c, chs[1:], sts[1:], v)
+            upc = 2 * c
+        else:
+            cb = chs[1]
+            total += 2.0 * v * (27 * c * cb + 27 * cb * cb + (c != cb) * c * cb)
+            upc = c + cb
+        total += 2.0 * vox * (27 * upc * outc / (s ** 3) + 27 * outc * outc)
+        return total
+    fwd = level(cin, K, list(channels), list(strides), 1.0)
+    if not train:
+        return fwd
+    s0 = strides[0]
+    first = 2.0 * (27 * cin * channels[0]) * 2 / (s0 ** 3)        # subunit 0 + residual conv of level 0
+    return 3.0 * fwd - first
+
+
+def conv_flops_per_voxel(eng, train: bool) -> float:
+    n = eng.net
+    return unet_conv_flops_per_voxel(n.channels, n.strides, n.in_channels, n.out_channels, train)
+
+
+def make_net(K, size, precision, device):
+    from segmantic_amd.seg.monai_unet import Net
+    net = Net(num_classes=K, num_channels=1, spatial_size=[size] * 3)
+    net.mixed_precision = precision == "bf16"
+    return net.to(device)
+
+
+def run_train(args, precision, rank, world, device, barrier, steps, warmup):
+    K = args.classes
+    net = make_net(K, args.size, precision, device).train()
+    if world > 1:
+        net.enable_grad_sync()
+    img, lab = synthetic(args.batch, args.size, K, rank, device)
+    batch = {"image": img, "label": lab}
+    for _ in range(warmup):
+        net.training_step(batch)
+    eng = net._engine
+    key = top_conv(eng).prefix + ":fwd"
+    eng.timed = {key}
+    eng.timings.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.training_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.timed = None
+    vox = args.batch * args.size ** 3
+    roof = roofline_of_top_conv(eng, key, vox, precision, eng._bufs["logits.t"]) if rank == 0 else None
+    fpv = conv_flops_per_voxel(eng, True)
+    return {"dt": dt, "units": vox * steps, "roofline": roof, "step_conv_flops": vox * fpv, "net": net}
+
+
+def run_infer(args, rank, device, barrier, steps, warmup):
+    from segmantic_amd.seg.inferers import group_factor, sliding_window_inference, window_starts
+    K, V = args.classes, args.volume
+    per_launch = args.sw_batch * group_factor()      # windows per forward of OUR network (inferers.py)
+    net = make_net(K, args.size, args.precision, device).eval()
+    g = torch.Generator().manual_seed(99 + rank)
+    vol = torch.randn((1, 1, V, V, V), generator=g).to(device)
+
+    def run():
+        with torch.no_grad():
+            return sliding_window_inference(vol, (args.size,) * 3, args.sw_batch, net, overlap=args.overlap,
+                                            return_labels=True, return_logits=False)
+    for _ in range(warmup):
+        run()
+    eng = net._engine
+    key = top_conv(eng).prefix + ":fwd"
+    eng.timed = {key}
+    eng.timings.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.timed = None
+    nwin = len(window_starts((V,) * 3, (args.size,) * 3, args.overlap))
+    xa = torch.empty((per_launch, args.size, args.size, args.size, eng.kpad), dtype=eng.dtype, device=device)
+    roof = roofline_of_top_conv(eng, key, per_launch * args.size ** 3, args.precision, xa, full_only=True)
+    del xa
+    if roof:
+        roof["kernel"] += (f"; {per_launch} windows per launch (sw_batch {args.sw_batch} x internal group "
+                           f"{group_factor()}), {nwin} windows per volume, two window groups in flight on two streams; "
+                           f"average over the full-size launches (the ragged last group of a volume is left out)")
+    fpv = conv_flops_per_voxel(eng, False)
+    return {"dt": dt, "steps": steps, "roofline": roof, "windows": nwin,
+            "conv_TFLOP_per_volume": nwin * args.size ** 3 * fpv / 1e12}
+
+
+def run_fit(args, rank, device, barrier, steps, warmup):
+    """training_step fed by the fit loop's sampler (seg/trainer.py: crops drawn by label class from
+    volumes cached in HBM, flips, SpatialPad) -- 2 volumes x num_samples 4 = the reference's batch"""
+    import numpy as np
+    from segmantic_amd.seg import trainer
+    K = args.classes
+    net = make_net(K, args.size, args.precision, device).train()
+    net.num_samples = args.batch // 2
+    V = max(args.size + 32, 160)
+    cache = trainer.CachedVolumes.__new__(trainer.CachedVolumes)
+    cache.items, cache.device = [], torch.device(device)
+    cache._stream = torch.cuda.Stream(device=device)
+    cache._pinned = torch.empty(4096, dtype=torch.int64).pin_memory()
+    for v in range(4):
+        img, lab = synthetic(1, V, K, 10 + v, device)
+        flat = lab.reshape(-1).long()
+        idx = [torch.nonzero(flat == c).reshape(-1) for c in range(K)]
+        counts = np.array([int(t.numel()) for t in idx], dtype=np.int64)
+        cache.items.append({"image": img[0], "label": lab[0], "class_all": torch.cat(idx),
+                            "class_counts": counts, "class_offsets": np.concatenate([[0], np.cumsum(counts)[:-1]]),
+                            "image_ndhwc": img[0].permute(1, 2, 3, 0).contiguous()[None],
+                            "label_dhw": lab[0, 0].contiguous()})
+    rng = np.random.RandomState(0)
+    order = [(2 * i % 4, (2 * i + 1) % 4) for i in range(warmup + steps)]
+    for i in range(warmup):
+        net.training_step(trainer.make_batch(net, cache, order[i], rng))
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        net.training_step(trainer.make_batch(net, cache, order[warmup + i], rng))
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"dt": dt, "units": args.batch * args.size ** 3 * steps, "volume": V}
+
+
 def main():
     args = parse()
     from segmantic_amd.seg.distributed import init_distributed
     rank, local_rank, world = init_distributed()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     import torch.distributed as dist
-
-    from segmantic_amd.seg.monai_unet import Net
-
-    K = args.classes
-    net = Net(num_classes=K, num_channels=1, spatial_size=[args.size] * 3)
-    net.mixed_precision = args.precision == "bf16"
-    net.to(device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -147,119 +345,117 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    top_key = "2.1.conv.unit0.conv:fwd"
-    if args.workload == "train":
-        net.train()
+    def maxdt(dt):
         if world > 1:
-            net.enable_grad_sync()
-        img, lab = synthetic(args.batch, args.size, K, rank, device)
-        batch = {"image": img, "label": lab}
-        for _ in range(args.warmup):
-            net.training_step(batch)
-        eng = net._engine
-        eng.timed = {top_key}
-        eng.timings.clear()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            net.training_step(batch)
-        barrier()
-        dt = time.perf_counter() - t0
-        units = args.batch * args.size ** 3 * args.steps
-        metric, unit = f"3D UNet train voxels/s on {args.size}^3 {args.precision}", "voxels/s"
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    K = args.classes
+    wl = args.workload
+    if wl == "all" and world > 1:
+        wl = "train"                      # the scaling runs time the training step only
+    out = None
+    if wl in ("all", "train"):
+        r = run_train(args, args.precision, rank, world, device, barrier, args.steps, args.warmup)
+        dt = maxdt(r["dt"])
         workload = (f"training_step (fwd + Dice + bwd + Adam) of the 5-level residual UNet, "
                     f"batch {args.batch} x 1ch x {args.size}^3, {K} labels, {args.precision}")
-        kern_units = args.batch * args.size ** 3
-        cfg = {"workload": workload, "global_batch": args.batch * world, "patch": args.size,
-               "labels": K, "parallelism": f"dp{world}"}
-    else:
-        net.eval()
-        from segmantic_amd.seg.inferers import sliding_window_inference
-        V = args.volume
-        g = torch.Generator().manual_seed(99 + rank)
-        vol = torch.randn((1, 1, V, V, V), generator=g).to(device)
-        wdt = torch.bfloat16 if net.mixed_precision else torch.float32
-
-        def run():
-            with torch.no_grad():
-                return sliding_window_inference(vol, (args.size,) * 3, args.sw_batch, net, overlap=args.overlap,
-                                                return_labels=True)
-        for _ in range(args.warmup):
-            run()
-        eng = net._engine
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        barrier()
-        dt = time.perf_counter() - t0
-        units = args.steps
-        metric, unit = "sliding-window infer vols/s", "volumes/s"
-        cfg = {"workload": f"sliding_window_inference of one {V}^3 volume, roi {args.size}^3, overlap "
-                           f"{args.overlap}, sw_batch {args.sw_batch}, {K} labels, {args.precision}, gather+forward+blend+argmax on device",
-               "parallelism": f"replicas{world}"}
-        kern_units = None
-
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = units * world / dt
-
-    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-           "config": cfg}
-
-    if rank == 0:
-        if args.workload == "train":
-            ms = eng.timing_ms(top_key)
-            if ms:
-                avg = statistics.mean(ms)
-                flops = kern_units * TOP_CONV_FLOP_PER_VOXEL
-                ach = flops / (avg * 1e-3) / 1e12
-                peak = MFMA_PEAK_BF16_TFLOPS if args.precision == "bf16" else MFMA_PEAK_F32_TFLOPS
-                es = 2 if args.precision == "bf16" else 4
-                # Algorithmic bytes per voxel of this launch: 16 channels in + 16 out (DESIGN.md
-                # section 4; the identity residual IS the input tensor and is taken from the LDS
-                # ring, so it is not a second stream).  Intensity 864*16/(32*es) = 216 FLOP/B
-                # (bf16) is below the chip ridge (~310 FLOP/B): HBM is the roof of this kernel.
-                abytes = kern_units * 16 * es * 2
-                gbps = abytes / (avg * 1e-3) / 1e9
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-                if (os.path.exists(tpath) and args.precision == "bf16" and args.batch == 8
-                        and args.size == 128 and K == 16):
-                    # PMC counters cannot be read from inside the process: measured offline with
-                    # rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)
-                    traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-                out["roofline"] = {
-                    "kernel": "segmi::conv_ring2_kernel<unsigned short, 16, 1, 0> -- forward launch of the "
-                              "full-resolution 16->16 k3 conv (identity residual from the LDS ring)",
-                    "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
-                    "frac": gbps / 8000.0, "traffic": traffic,
-                    "avg_launch_ms": avg, "launches": len(ms),
-                    "fused_into_this_launch": "BatchNorm-apply + PReLU of the producer layer (segmi_in_affine; "
-                                              "SEGMI_FUSE_BN=0 restores the separate 1.07 GB, 0.225 ms pass, "
-                                              "this launch then takes 0.285 ms = frac 0.47 and the step 2.5 % longer; "
-                                              "the same kernel's input-gradient launch, which has no transform, runs "
-                                              "0.284 ms in the serial trace under profiles/)",
-                    "algorithmic_bytes_per_launch": abytes,
-                    "mfma_view": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
-                                  "peak_TFLOPs": peak, "frac": ach / peak},
-                }
-            step_flops = args.batch * args.size ** 3 * FLOP_PER_VOXEL_TRAIN_K16 if K == 16 else None
-            if step_flops:
-                out["config"]["step_conv_TFLOPs"] = step_flops / 1e12
-                out["config"]["whole_step_TFLOP_per_s_per_gpu"] = step_flops / (dt / args.steps) / 1e12
-        if world == 1 and not args.no_cpu_baseline:
+        out = {"metric": f"3D UNet train voxels/s on {args.size}^3 {args.precision}",
+               "value": r["units"] * world / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": workload, "global_batch": args.batch * world, "patch": args.size,
+                          "labels": K, "parallelism": f"dp{world}",
+                          "step_conv_TFLOPs": r["step_conv_flops"] / 1e12,
+                          "whole_step_TFLOP_per_s_per_gpu": r["step_conv_flops"] / (dt / args.steps) / 1e12}}
+        if rank == 0 and r["roofline"]:
+            r["roofline"]["traffic"] = pmc_traffic("train_top_conv_fwd_hbm_bytes_per_launch") \
+                if (args.precision, args.batch, args.size, K) == ("bf16", 8, 128, 16) else None
+            r["roofline"]["fused_into_this_launch"] = (
+                "BatchNorm-apply + PReLU of the producer layer (segmi_in_affine): the normalised tensor is never "
+                "written; SEGMI_FUSE_BN=0 restores the separate pass")
+            out["roofline"] = r["roofline"]
+        del r
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             try:
-                if args.workload == "train":
-                    out["cpu_baseline"] = cpu_baseline_train(args.cpu_size, K)
-                else:
-                    out["cpu_baseline"] = cpu_baseline_infer(K)
-            except Exception as e:  # the baseline is informative; never lose the GPU number
+                out["cpu_baseline"] = cpu_baseline_train(args.cpu_size, K)
+            except Exception as e:      # the baseline is informative; never lose the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+    if wl in ("all", "infer"):
+        try:
+            r = run_infer(args, rank, device, barrier, args.infer_steps if wl == "all" else args.steps,
+                          1 if wl == "all" else args.warmup)
+            dt = maxdt(r["dt"])
+            V = args.volume
+            inf = {"metric": "sliding-window infer vols/s", "value": r["steps"] * world / dt, "unit": "volumes/s",
+                   "steps": r["steps"], "ms_per_volume": dt / r["steps"] * 1e3, "dtype": args.precision,
+                   "config": {"workload": f"sliding_window_inference of one {V}^3 volume, roi {args.size}^3, overlap "
+                                          f"{args.overlap}, sw_batch {args.sw_batch}, {K} labels, {args.precision}: "
+                                          f"gather + {r['windows']} window forwards + ordered blend + argmax on device",
+                              "conv_TFLOP_per_volume": r["conv_TFLOP_per_volume"],
+                              "conv_TFLOP_per_s": r["conv_TFLOP_per_volume"] * r["steps"] / dt,
+                              "parallelism": f"replicas{world}"},
+                   "roofline": r["roofline"]}
+            if inf["roofline"]:
+                inf["roofline"]["traffic"] = pmc_traffic("infer_top_conv_fwd_hbm_bytes_per_launch")
+            del r
+            torch.cuda.empty_cache()
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                try:
+                    inf["cpu_baseline"] = cpu_baseline_infer(K)
+                except Exception as e:
+                    inf["cpu_baseline"] = {"error": repr(e)}
+        except Exception as e:
+            if wl == "infer":
+                raise
+            inf = {"error": repr(e)}
+        if wl == "infer":
+            out = {"metric": inf["metric"], "value": inf["value"], "unit": inf["unit"], "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": inf["ms_per_volume"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                   "data": "synthetic", "config": inf["config"], "roofline": inf["roofline"]}
+            if "cpu_baseline" in inf:
+                out["cpu_baseline"] = inf["cpu_baseline"]
+        else:
+            out["infer"] = inf
+    if wl == "all":
+        try:
+            r = run_train(args, "f32", rank, world, device, barrier, max(2, args.steps // 3), 2)
+            n = max(2, args.steps // 3)
+            out["f32_parity_mode"] = {
+                "what": "the same training step with f32 storage and exact-f32 MFMA chains (mixed_precision: false): "
+                        "the mode whose logits meet north_star's 1e-3 tolerance against the CPU oracle "
+                        "(tests/test_unet_gpu.py asserts 2e-4); the bf16 headline path is gated at 6e-2 / 97 % argmax",
+                "value": r["units"] / r["dt"], "unit": "voxels/s", "ms_per_step": r["dt"] / n * 1e3, "steps": n,
+                "dtype": "f32", "roofline": r["roofline"]}
+            del r
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["f32_parity_mode"] = {"error": repr(e)}
+    if wl in ("all", "fit"):
+        try:
+            r = run_fit(args, rank, device, barrier, args.steps, args.warmup)
+            dt = maxdt(r["dt"])
+            fit = {"what": f"training_step fed by the fit loop's on-GPU sampler (4 cached {r['volume']}^3 volumes, 2 volumes x "
+                           f"{args.batch // 2} label-class crops + flips per step) instead of a fixed batch",
+                   "value": r["units"] * world / dt, "unit": "voxels/s", "ms_per_step": dt / args.steps * 1e3,
+                   "steps": args.steps, "dtype": args.precision}
+            if wl == "fit":
+                out = {"metric": f"3D UNet fit (sampler + step) voxels/s on {args.size}^3 {args.precision}",
+                       "value": fit["value"], "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                       "warmup": args.warmup, "ms_per_step": fit["ms_per_step"], "higher_is_better": True,
+                       "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                       "config": {"workload": fit["what"], "parallelism": f"dp{world}"}}
+            else:
+                out["fit"] = fit
+        except Exception as e:
+            if wl == "fit":
+                raise
+            out["fit"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -95,6 +95,10 @@ typedef struct segmi_in_affine {
   const float* shift;
   const float* prelu_alpha;
 } segmi_in_affine;
+/* Which forward kernel family segmi_conv3d_fwd() runs for this layer shape: a static string such as
+ * "conv_ring2_kernel<bf16, CK=16, NT=1>" (reports / benchmarks label their roofline line with it). */
+const char* segmi_conv3d_fwd_kernel_name(int dtype, const segmi_act* in, const segmi_act* out,
+                                         int ksize, int stride);
 int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                               int stride);
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,

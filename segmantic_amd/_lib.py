@@ -59,6 +59,7 @@ SIGNATURES = {
     "segmi_wpack_batch": (_i, [_i, C.POINTER(WpackDesc), _i, _P, _i, _P]),
     "segmi_conv3d_stats_rows": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_in_affine_ok": (_i, [_i, _AP, _AP, _i, _i]),
+    "segmi_conv3d_fwd_kernel_name": (C.c_char_p, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_split_act_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_fwd_split_act": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _i, _i, _P]),
     "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, C.POINTER(InAffine), _P]),

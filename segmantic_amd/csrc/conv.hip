@@ -210,6 +210,27 @@ int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* 
   return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st) : conv_mfma_bf16(p, ksize, stride, st);
 }
 
+const char* segmi_conv3d_fwd_kernel_name(int dtype, const segmi_act* in, const segmi_act* out,
+                                         int ksize, int stride) {
+  static thread_local char buf[96];
+  if (!act_ok(in) || !act_ok(out)) return "invalid";
+  const char* dt = dtype == SEGMI_BF16 ? "bf16" : "f32";
+  if (mfma_ok(in->c, out->c)) {
+    const int ck = pick_ck(dtype, in->c);
+    if (conv_ring_ok(dtype, in->c, ksize, stride, out))
+      snprintf(buf, sizeof buf, "conv_ring2_kernel<%s, CK=%d, NT=%d>", dt, ck,
+               ck == 32 && (out->c / 16) % 2 == 0 ? 2 : 1);
+    else if (conv_ks_ok(dtype, in->c, ksize, stride))
+      snprintf(buf, sizeof buf, "conv_fwd_ks_kernel<%s, k%d s%d>", dt, ksize, stride);
+    else
+      snprintf(buf, sizeof buf, "conv_fwd_mfma_kernel<%s, CK=%d, k%d s%d>", dt, ck, ksize, stride);
+    return buf;
+  }
+  if (small_fwd_eligible(dtype, in, out, ksize)) snprintf(buf, sizeof buf, "conv_small_fwd_kernel<%s>", dt);
+  else snprintf(buf, sizeof buf, "conv_direct_kernel<%s>", dt);
+  return buf;
+}
+
 int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                               int stride) {
   if (!act_ok(in) || !act_ok(out) || dtype != SEGMI_BF16 || !mfma_ok(in->c, out->c)) return 0;

@@ -140,6 +140,12 @@ def _in_affine(in_tf):
     return C.byref(InAffine(_ptr(scale), _ptr(shift), _ptr(alpha)))
 
 
+def conv3d_fwd_kernel_name(x, y, ksize, stride) -> str:
+    """kernel family ``conv3d_fwd`` runs for this layer (for benchmark / report labels)"""
+    ax, ay = act(x), act(y)
+    return lib.segmi_conv3d_fwd_kernel_name(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride).decode()
+
+
 def conv3d_in_affine_ok(x, y, ksize, stride) -> bool:
     ax, ay = act(x), act(y)
     return bool(lib.segmi_conv3d_in_affine_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))

@@ -71,6 +71,8 @@ class Net(torch.nn.Module):
     augment_intensity: bool = False
     augment_spatial: bool = False
     num_samples: int = 4
+    flip_prob: float = 0.2            # RandFlipd(prob=0.2) per axis, reference :214-217
+    train_spacing: list = []          # Spacingd(pixdim) of a configured training pre-processing
     optimizer: dict = {"optimizer": "Adam", "lr": 1e-4, "momentum": 0.9, "epsilon": 1e-8,
                        "amsgrad": False, "weight_decouple": False}
     lr_scheduling: dict = {"scheduler": "Constant", "factor": 0.5, "patience": 10, "T_0": 50,
@@ -377,15 +379,37 @@ def train(
         net.dataset = PairedDataSet.load_from_json(datalist)
     else:
         raise ValueError("Either provide a dataset file, or an image_dir, labels_dir pair.")
-    if preprocessing or augmentation:
-        raise NotImplementedError(
-            "segmantic_amd: MONAI-bundle 'preprocessing' / 'augmentation' dictionaries need MONAI's "
-            "ConfigParser; leave them empty to use the built-in default pipeline")
     net.config_preprocessing = preprocessing
     net.config_augmentation = augmentation
     net.augment_intensity = augment_intensity
     net.augment_spatial = augment_spatial
     net.num_samples = num_samples
+    # MONAI-bundle dictionaries (reference prepare_data, :232-262): resolved with the reference's
+    # parser context and mapped onto the on-device pipeline; transforms it cannot express raise here
+    from ..utils.bundle import ConfigParser, plan_augmentation, plan_preprocessing
+    if preprocessing:
+        parser = ConfigParser({"image_key": "image", "label_key": "label", "preprocessing": preprocessing})
+        parser.parse(True)
+        plan = plan_preprocessing(parser.get_parsed_content("preprocessing"))
+        if plan is None:
+            print("Using default preprocessing")
+        else:
+            missing = [k for k in ("orientation", "normalize", "crop_foreground") if not plan[k]]
+            if missing:
+                raise ValueError(f"'preprocessing': the on-device pipeline always runs {missing}; add the "
+                                 "corresponding transforms or leave 'preprocessing' empty")
+            net.train_spacing = plan["spacing"]
+    if augmentation:
+        parser = ConfigParser({"image_key": "image", "label_key": "label", "augmentation": augmentation})
+        parser.parse(True)
+        plan = plan_augmentation(parser.get_parsed_content("augmentation"))
+        if plan is not None:
+            net.num_samples = plan["num_samples"]
+            net.flip_prob = plan["flip_prob"]
+            net.augment_spatial = net.augment_spatial or plan["augment_spatial"]
+            net.augment_intensity = net.augment_intensity or plan["augment_intensity"]
+            if plan["spatial_size"] and not spatial_size:
+                net.spatial_size = [int(v) for v in plan["spatial_size"]]
     net.optimizer = optimizer
     net.lr_scheduling = lr_scheduling
     net.cache_rate = cache_rate

@@ -35,8 +35,8 @@ class CachedVolumes:
     sampler stream + one pinned D2H copy: the training stream is never synchronised by the
     sampler (a ``.cpu()`` on the training stream would drain the whole step pipeline)."""
 
-    def __init__(self, files, device, num_classes: int):
-        pipe = PredictPipeline(device=device, spacing=(), with_label=True)
+    def __init__(self, files, device, num_classes: int, spacing=()):
+        pipe = PredictPipeline(device=device, spacing=spacing, with_label=True)
         self.items = []
         self.device = torch.device(device)
         self._stream = torch.cuda.Stream(device=self.device)
@@ -133,7 +133,8 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
         src = it["image_ndhwc"]                                              # NDHWC, n = 1
         out_i = torch.empty((len(starts), roi[0], roi[1], roi[2], C), dtype=torch.float32, device=dev)
         out_l = torch.empty((len(starts), roi[0], roi[1], roi[2]), dtype=torch.float32, device=dev)
-        flips = [(int(rng.rand() < 0.2)) | (int(rng.rand() < 0.2) << 1) | (int(rng.rand() < 0.2) << 2)
+        fp = float(getattr(net, "flip_prob", 0.2))
+        flips = [(int(rng.rand() < fp)) | (int(rng.rand() < fp) << 1) | (int(rng.rand() < fp) << 2)
                  for _ in starts]
         if spatial is None:
             ops.crop_patches(src, it["label_dhw"], [[0] + s for s in starts], flips, out_i, out_l)
@@ -273,8 +274,9 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
         dist.broadcast(net._engine.flat, src=0)
     print(f"[rank {rank}/{world}] caching data on {device} "
           f"({len(net.dataset.training_files())} train / {len(net.dataset.validation_files())} val volumes)")
-    train_cache = CachedVolumes(net.dataset.training_files(), device, net.num_classes)
-    val_cache = CachedVolumes(net.dataset.validation_files(), device, net.num_classes)
+    spacing = list(getattr(net, "train_spacing", []) or [])
+    train_cache = CachedVolumes(net.dataset.training_files(), device, net.num_classes, spacing)
+    val_cache = CachedVolumes(net.dataset.validation_files(), device, net.num_classes, spacing)
 
     def step_fn(vol_ids, rng):                    # set_determinism(seed=0), reference :229
         return net.training_step(make_batch(net, train_cache, vol_ids, rng))["loss"]

@@ -814,8 +814,8 @@ class UNetEngine:
                 continue
             if bn is None:
                 self._join_branch(br)
-                ops.conv3d_fwd(cur, out, conv.fwd_pack(), conv.w, 0, conv.b, conv.k, conv.stride,
-                               residual=resid)
+                self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, cur, out, conv.fwd_pack(), conv.w, 0,
+                            conv.b, conv.k, conv.stride, residual=resid)
                 break
             sc, sh = bn.eval_affine()
             pack, wsrc, bias = conv.folded(sc, sh)
