@@ -95,6 +95,27 @@ typedef struct segmi_in_affine {
   const float* shift;
   const float* prelu_alpha;
 } segmi_in_affine;
+/* Optional epilogue of an INPUT-GRADIENT convolution (segmi_conv3d_fwd with a kind-1 pack) whose
+ * output `out` is the gradient g flowing into a training-mode BatchNorm + PReLU: with x = that
+ * layer's forward input (the raw output of its producer conv, same extents as `out`) the kernel
+ * also accumulates the three per-channel sums that segmi_bn_act_bwd_reduce would compute from
+ * (g, x) in a separate 2-tensor pass -- sum dz, sum dz*xhat, sum g*z[z<=0] -- taken of the STORED
+ * (rounded) gradient, one partial row per workgroup: partials f32 [rows][3][c] with rows =
+ * segmi_conv3d_stats_rows(in, out, ksize, stride); feed them to segmi_bn_act_bwd_finalize.
+ * segmi_conv3d_bn_bwd_sums_ok() says whether the layer's kernel implements it (bf16 z-marching
+ * ring, 16 -> 16 channels); pass NULL otherwise.  Replaces autograd's separate BatchNorm / PReLU
+ * backward reductions under monai ADN, monai_unet.py:114-124, 345. */
+typedef struct segmi_bn_bwd_sums {
+  const segmi_act* x;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;        /* nullable = 1 */
+  const float* beta;         /* nullable = 0 */
+  const float* prelu_alpha;  /* nullable = no activation */
+  float* partials;
+} segmi_bn_bwd_sums;
+int segmi_conv3d_bn_bwd_sums_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                                int stride);
 /* Which forward kernel family segmi_conv3d_fwd() runs for this layer shape: a static string such as
  * "conv_ring2_kernel<bf16, CK=16, NT=1>" (reports / benchmarks label their roofline line with it). */
 const char* segmi_conv3d_fwd_kernel_name(int dtype, const segmi_act* in, const segmi_act* out,
@@ -105,7 +126,7 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
                      float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
-                     void* stream);
+                     const segmi_bn_bwd_sums* bn_bwd /* nullable */, void* stream);
 /* The first ResidualUnit of the network convolves its (<= 4 channel) input twice with the same
  * geometry: subunit 0 (k3, stride s) and the residual convolution (k3, stride s).  One launch
  * stages the input once and produces both:  out_a = prelu_a(conv_a(in) + bias_a) with optional

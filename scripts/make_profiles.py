@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -32,10 +32,10 @@ for wl, name in (("train", "train_b8_128_bf16"), ("infer", "infer_512_bf16")):
     shutil.copy(st, os.path.join(OUT, f"{tag}_{name}_kernel_stats.csv"))
     steps = "13" if wl == "train" else "3"
     open(os.path.join(OUT, f"{tag}_{name}_kernel_stats.txt"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload infer --steps 2 --warmup 1' if wl == 'infer' else '--steps 10 --warmup 3'} --no-cpu-baseline\n"
+        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload infer --steps 2 --warmup 1' if wl == 'infer' else '--workload train --steps 10 --warmup 3'} --no-cpu-baseline\n"
         f"# (both streams overlapped; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
         + run("kstats.py", st, steps))
-    shutil.copy(os.path.join(SRC, f"bench_{wl}.json"), os.path.join(OUT, f"{tag}_bench_{wl}.json"))
+shutil.copy(os.path.join(SRC, "bench_all.json"), os.path.join(OUT, f"{tag}_bench_all.json"))
 
 t = newest("ser_time/*/*kernel_trace.csv")
 f = newest("ser_fetch/*/*counter_collection.csv")
@@ -46,29 +46,40 @@ open(os.path.join(OUT, f"{tag}_train_b8_128_bf16_last_step_by_grid.txt"), "w").w
     run("grid_table.py", newest("train_stats/*/*kernel_trace.csv")))
 
 
-def top_ring2(path):
-    """counter of the forward full-resolution ring2 launch: first PLAIN ring2 dispatch of 1024 workgroups
-    after the last-but-one adam_kernel (= inside the last step)"""
+def launches(path, substr, grid):
+    """counter values of the dispatches of a kernel (name substring, total threads) in time order"""
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-    lo = marks[-2] if len(marks) > 1 else 0
-    for r in rows[lo:]:
-        if "conv_ring2_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) == 262144:
-            return float(r["Counter_Value"]), r["Kernel_Name"]
-    raise SystemExit("no full-resolution ring2 dispatch found")
+    return [(float(r["Counter_Value"]), r["Kernel_Name"]) for r in rows
+            if substr in r["Kernel_Name"] and int(r["Grid_Size"]) == grid]
 
 
-fk, kname = top_ring2(f)
-wk, _ = top_ring2(w)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc_hash: stamps the measurement to the kernel sources it was taken on)
+
+# training: forward launch of the full-resolution 16 -> 16 conv = first PLAIN ring2 dispatch of 1024
+# workgroups of a step (the second one is the input-gradient launch); batch 8 x 128^3
+fk, kname = launches(f, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 262144)[-2]
+wk, _ = launches(w, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 262144)[-2]
 alg = 8 * 128 ** 3 * 16 * 2 * 2
+# inference: the same layer on a full group of 16 windows (2048 workgroups)
+fi = newest("inf_fetch/*/*counter_collection.csv")
+wi = newest("inf_write/*/*counter_collection.csv")
+fki = [v for v, _ in launches(fi, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 524288)]
+wki = [v for v, _ in launches(wi, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 524288)]
+fki, wki = sorted(fki)[len(fki) // 2], sorted(wki)[len(wki) // 2]
+alg_i = 16 * 128 ** 3 * 16 * 2 * 2
 json.dump({
-    "kernel": kname + " (full-resolution 16->16 k3 conv forward with identity residual from LDS, batch 8 x 128^3)",
+    "source_hash": bench.csrc_hash(),
+    "kernel": kname + " (full-resolution 16->16 k3 conv forward with identity residual from LDS)",
     "command": "SEGMI_SERIAL=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py "
-               "--steps 1 --warmup 1 --no-cpu-baseline ; same with --pmc WRITE_SIZE (separate passes; scripts/gpu_profiles.sh)",
-    "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
-    "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced streaming reads (MI355X_MICROARCH.md HBM section; "
-                  "confirmed here on bn_act_fwd: 2.62e5 KB reported for a 537 MB read) -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
-    "hbm_bytes_per_launch": (2 * fk + wk) * 1024, "algorithmic_bytes_per_launch": alg,
-    "note": "reads exceed the 537 MB input by the (8+2)x(16+2)/(8x16) y/x halo of neighbouring columns that miss L2; writes are exact",
+               "--workload train --steps 1 --warmup 1 --no-cpu-baseline ; same with --pmc WRITE_SIZE (separate passes); "
+               "inference: the same two passes of --workload infer (scripts/gpu_profiles.sh)",
+    "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced streaming reads (MI355X_MICROARCH.md HBM section) "
+                  "-> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+    "train_FETCH_SIZE_KB": fk, "train_WRITE_SIZE_KB": wk,
+    "train_top_conv_fwd_hbm_bytes_per_launch": (2 * fk + wk) * 1024, "train_algorithmic_bytes_per_launch": alg,
+    "infer_FETCH_SIZE_KB": fki, "infer_WRITE_SIZE_KB": wki,
+    "infer_top_conv_fwd_hbm_bytes_per_launch": (2 * fki + wki) * 1024, "infer_algorithmic_bytes_per_launch": alg_i,
+    "note": "reads exceed the input by the (8+2)x(16+2)/(8x16) y/x halo of neighbouring columns that miss L2; writes are exact",
 }, open(os.path.join(OUT, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print("profiles written:", sorted(os.listdir(OUT)))

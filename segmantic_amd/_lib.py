@@ -43,6 +43,13 @@ class InAffine(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("prelu_alpha", C.c_void_p)]
 
 
+class BnBwdSums(C.Structure):
+    """``segmi_bn_bwd_sums``: BatchNorm-backward reduction fused into an input-gradient conv's epilogue."""
+
+    _fields_ = [("x", C.POINTER(Act)), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("prelu_alpha", C.c_void_p), ("partials", C.c_void_p)]
+
+
 _P = C.c_void_p
 _AP = C.POINTER(Act)
 _i = C.c_int
@@ -62,7 +69,9 @@ SIGNATURES = {
     "segmi_conv3d_fwd_kernel_name": (C.c_char_p, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_split_act_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_fwd_split_act": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _i, _i, _P]),
-    "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, C.POINTER(InAffine), _P]),
+    "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, C.POINTER(InAffine),
+                              C.POINTER(BnBwdSums), _P]),
+    "segmi_conv3d_bn_bwd_sums_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_pair_ok": (_i, [_i, _AP, _AP, _AP]),
     "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),

@@ -238,11 +238,26 @@ int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* o
   return ksize == 3 && stride == 1 && conv_ring_ok(dtype, in->c, ksize, stride, out) ? 1 : 0;
 }
 
+int segmi_conv3d_bn_bwd_sums_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
+                                int stride) {
+  if (!act_ok(in) || !act_ok(out) || dtype != SEGMI_BF16) return 0;
+  // the ring kernel's 16-channel single-tile variant (conv_ring2_kernel<bf16, 16, 1, MODE 4>)
+  return in->c == 16 && out->c == 16 && ksize == 3 && stride == 1 &&
+                 conv_ring_ok(dtype, in->c, ksize, stride, out) ? 1 : 0;
+}
+
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
                      float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
-                     void* stream) {
+                     const segmi_bn_bwd_sums* bn_bwd, void* stream) {
+  if (bn_bwd)
+    SEGMI_CHECK_ARG(bn_bwd->x && act_ok(bn_bwd->x) && bn_bwd->mean && bn_bwd->invstd && bn_bwd->partials &&
+                        segmi_conv3d_bn_bwd_sums_ok(dtype, in, out, ksize, stride) && !prelu_alpha &&
+                        !stats_partials && bn_bwd->x->n == out->n && bn_bwd->x->d == out->d &&
+                        bn_bwd->x->h == out->h && bn_bwd->x->w == out->w && bn_bwd->x->c == out->c &&
+                        bn_bwd->x->ld % 4 == 0 && ((uintptr_t)bn_bwd->x->data % 8) == 0,
+                    "conv3d: this launch cannot take BatchNorm-backward sums (ask segmi_conv3d_bn_bwd_sums_ok)");
   if (in_tf)
     SEGMI_CHECK_ARG(in_tf->scale && in_tf->shift && segmi_conv3d_in_affine_ok(dtype, in, out, ksize, stride),
                     "conv3d: this layer cannot take an input transform (ask segmi_conv3d_in_affine_ok)");
@@ -280,6 +295,12 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
     p.nchunks = in->c / pick_ck(dtype, in->c);
     p.ntiles_total = out->c / 16;
     if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
+    if (bn_bwd) {
+      p.bx = bn_bwd->x->data; p.ldbx = bn_bwd->x->ld; p.bmean = bn_bwd->mean; p.binvstd = bn_bwd->invstd;
+      p.bgamma = bn_bwd->gamma; p.bbeta = bn_bwd->beta; p.balpha = bn_bwd->prelu_alpha;
+      p.bpart = bn_bwd->partials;
+      SEGMI_CHECK_ARG((int64_t)p.Ho * p.Wo * p.ldbx < (1ll << 31), "conv3d: plane too large for 32-bit offsets");
+    }
     return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st)
                               : conv_mfma_bf16(p, ksize, stride, st);
   }

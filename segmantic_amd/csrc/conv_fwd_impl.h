@@ -33,6 +33,14 @@ struct ConvParams {
   // two convolutions of one input as ONE launch with 2c outputs of which the first c are activated.
   // Honoured by the tile kernel (conv_fwd_mfma_kernel) only.
   int act_tiles;
+  // optional BatchNorm-backward sums in the epilogue (segmi_bn_bwd_sums; ring kernel, MODE 4): the
+  // launch is an input-gradient convolution whose OUTPUT is the gradient g flowing into a training-
+  // mode BatchNorm + PReLU; with that layer's forward input bx the epilogue accumulates the three
+  // per-channel sums of bn_act_bwd_reduce (sum dz, sum dz*xhat, sum g*z[z<=0]) into bpart[rows][3][c]
+  const void* bx;
+  int ldbx;
+  const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta; const float* balpha;
+  float* bpart;
   int dbg;   // diagnostics only (SEGMI_RING2_DBG): 1 = no staging loads, 2 = no stores, 4 = no MFMA loop
 };
 

@@ -32,6 +32,8 @@
 
 namespace segmi {
 
+// MODE 4 = PLAIN + the BatchNorm-backward sums of the layer the output gradient flows into
+// (ConvParams::bpart; see there).
 // MODE: bit 0 = PReLU, bit 1 = BatchNorm statistics -- compile-time, because every epilogue
 // instruction is an issue turn of the wave.  0 ("PLAIN": the two full-resolution launches of a
 // training step and every input-gradient launch) is bias + residual + convert only, 1 the
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     touch_v(bias4[jt]);
   }
   constexpr bool PLAIN = MODE == 0;
+  constexpr bool BSUM = MODE == 4;
   constexpr bool has_alpha = (MODE & 1) != 0;
   float alpha = has_alpha ? *p.alpha : 0.f;
   touch_s(alpha);
@@ -181,6 +184,28 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   f32x4 ssum[NT], ssq[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) { ssum[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // MODE 4: sums of the BatchNorm backward of the layer behind the output; its parameters for the
+  // lane's 4 channels sit in LDS behind the input-transform slots and are re-read every step
+  f32x4 bs0[NT], bs1[NT], bs2[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) { bs0[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; bs1[jt] = bs0[jt]; bs2[jt] = bs0[jt]; }
+  // z = xhat*gamma + beta = x*sc + sh with sc = invstd*gamma, sh = beta - mean*sc; sum dz*xhat is
+  // accumulated as sum dz*x and turned into invstd * (sum dz*x - mean * sum dz) per workgroup row
+  float* bprm = tfs + 2 * CK;                       // [4][NT*16]: mean, invstd, sc, sh
+  float balpha = 1.f;
+  if constexpr (BSUM) {
+    if (tid < 4 * NT * 16) {
+      const int which = tid / (NT * 16), ch = nt0 * 16 + tid % (NT * 16);
+      const float mean = p.bmean[ch], istd = p.binvstd[ch];
+      const float sc = istd * (p.bgamma ? p.bgamma[ch] : 1.f);
+      bprm[tid] = which == 0 ? mean : which == 1 ? istd : which == 2 ? sc : fmaf(-mean, sc, p.bbeta ? p.bbeta[ch] : 0.f);
+    }
+    balpha = p.balpha ? *p.balpha : 1.f;
+    touch_s(balpha);
+    __syncthreads();
+  }
+  const bool b_has_alpha = BSUM && p.balpha != nullptr;
+  const T* bxp = (const T*)p.bx;
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.res;
   // identity residual (out = conv(x) + x): the rows are the centre plane of the ring
@@ -197,6 +222,10 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     r_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldr + co);
   }
   const int64_t oplane = (int64_t)p.Ho * p.Wo * p.ldo, rplane = (int64_t)p.Ho * p.Wo * p.ldr;
+  unsigned b_off[2];
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro) b_off[ro] = (unsigned)(((oy0 + 2 * wave + ro) * p.Wo + ox0 + r) * p.ldbx + co);
+  const int64_t bplane = (int64_t)p.Ho * p.Wo * p.ldbx;
 
   for (int step = 0; step < nsteps_z; ++step) {
     const int zb = step * G::TD;
@@ -232,6 +261,21 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
                                                          : typename Raw4<T>::type{};
       }
     }
+    // MODE 4: the BatchNorm's forward input at this step's output voxels.  Planes 0, 1 are fetched
+    // here (under the MFMA loop), planes 2, 3 once the staging registers are free (under the
+    // epilogue of planes 0, 1): all four up front do not fit the 256-register budget
+    typename Raw4<T>::type bxv[BSUM ? 4 : 1][2][NT];
+    auto fetch_bx = [&](int zi) {
+      const int oz = z0 + zb + zi;
+      const T* bp = bxp + ((int64_t)n * p.Do + oz) * bplane;
+#pragma unroll
+      for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          bxv[BSUM ? zi : 0][ro][jt] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(bp + b_off[ro] + jt * 16)
+                                                                 : typename Raw4<T>::type{};
+    };
+    if constexpr (BSUM) { fetch_bx(0); fetch_bx(1); }
     // ---- compute: input plane c (z = zb - 1 + c) lives in ring slot (zb + c) % R
     // (no zero-initialisation: the first MFMA into an accumulator takes the literal 0 as C)
     f32x4 acc[4][2][NT];
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     // software pipeline over the (plane, k-step) iterations, fragments PD iterations ahead (an
     // iteration is 2 - 6 MFMAs = 32 - 96 clk against >= 128 clk of loaded LDS latency; the depth is
     // what the variant's register budget allows)
-    constexpr int PD = CK == 16 ? (MODE == 3 ? 3 : 4) : (NT == 1 ? 4 : 2);
+    constexpr int PD = CK == 16 ? (MODE == 3 ? 3 : (MODE == 4 ? 2 : 4)) : (NT == 1 ? 4 : 2);
     frag_t a[PD + 1][2];
     auto issue = [&](int it, frag_t (&dst)[2]) {
       const int c = it / J, j = it % J;
@@ -322,6 +366,21 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
             for (int jt = 0; jt < NT; ++jt) touch_v(resv[zi][ro][jt]);
       }
     }
+    f32x4 bsc4[NT], bsh4[NT];
+    if constexpr (BSUM) {
+      fetch_bx(2); fetch_bx(3);
+#pragma unroll
+      for (int zi = 0; zi < 2; ++zi)
+#pragma unroll
+        for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) touch_v(bxv[zi][ro][jt]);
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        bsc4[jt] = *reinterpret_cast<const f32x4*>(bprm + 2 * NT * 16 + jt * 16 + 4 * g);
+        bsh4[jt] = *reinterpret_cast<const f32x4*>(bprm + 3 * NT * 16 + jt * 16 + 4 * g);
+      }
+    }
     // ---- epilogue of this step
 #pragma unroll
     for (int zi = 0; zi < 4; ++zi) {
@@ -359,6 +418,23 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
               for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
             }
             if (resp) v += Raw4<T>::cvt(resv[rz][ro][jt]);
+            if constexpr (BSUM) {
+              // the sums are taken of the STORED gradient (bf16-rounded), as the separate pass reads it
+              u32x2 o;
+              o[0] = pack_bf16x2(v[0], v[1]);
+              o[1] = pack_bf16x2(v[2], v[3]);
+              *reinterpret_cast<u32x2*>(op + o_off[ro] + jt * 16) = o;
+              const f32x4 d = Raw4<T>::cvt(o);
+              const f32x4 xr = Raw4<T>::cvt(bxv[zi][ro][jt]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float z = fmaf(xr[e], bsc4[jt][e], bsh4[jt][e]);
+                float dz = d[e];
+                if (b_has_alpha && !(z > 0.f)) { bs2[jt][e] = fmaf(d[e], z, bs2[jt][e]); dz = balpha * d[e]; }
+                bs0[jt][e] += dz;
+                bs1[jt][e] = fmaf(dz, xr[e], bs1[jt][e]);
+              }
+            } else
             store4<T>(op + o_off[ro] + jt * 16, v);
           }
         }
@@ -366,6 +442,36 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     __syncthreads();
   }
 
+  if constexpr (BSUM) {
+    float* red = reinterpret_cast<float*>(smem);  // [wave][3][NT*16]  (ring no longer needed)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = row16_sum(bs0[jt][e]);
+        const float a1 = row16_sum(bs1[jt][e]);
+        const float a2 = row16_sum(bs2[jt][e]);
+        if (r == 0) {
+          red[(wave * 3 + 0) * NT * 16 + jt * 16 + 4 * g + e] = a0;
+          red[(wave * 3 + 1) * NT * 16 + jt * 16 + 4 * g + e] = a1;
+          red[(wave * 3 + 2) * NT * 16 + jt * 16 + 4 * g + e] = a2;
+        }
+      }
+    __syncthreads();
+    if (tid < 3 * NT * 16) {
+      const int which = tid / (NT * 16), ch = tid % (NT * 16);
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sacc += red[(w * 3 + which) * NT * 16 + ch];
+      if (which == 1) {           // sum dz*x -> sum dz*xhat
+        float s0 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s0 += red[(w * 3 + 0) * NT * 16 + ch];
+        sacc = bprm[1 * NT * 16 + ch] * fmaf(-bprm[ch], s0, sacc);
+      }
+      p.bpart[((int64_t)blockIdx.x * 3 + which) * p.Cout + nt0 * 16 + ch] = sacc;
+    }
+  }
   if (want_stats) {
     float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]  (ring no longer needed)
 #pragma unroll
@@ -406,18 +512,21 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
   auto kern = conv_ring2_kernel<T, CK, NT, MODE>;
   static bool attr_done = false;
-  if (!attr_done && G::LDS_BYTES + 2 * CK * 4 > 64 * 1024) {
+  if (!attr_done && G::LDS_BYTES + 6 * CK * 4 > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + 2 * CK * 4);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + 6 * CK * 4);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES + 2 * CK * 4, st, p);
+  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES + 6 * CK * 4, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(ring2)");
   return SEGMI_OK;
 }
 
 template <typename T, int CK, int NT>
 static int launch_conv_ring2_cfg(const ConvParams& p, hipStream_t st) {
+  if constexpr (CK == 16 && NT == 1) {
+    if (p.bpart && !p.alpha && !p.stats) return launch_conv_ring2_k<T, CK, NT, 4>(p, st);
+  }
   switch ((p.alpha ? 1 : 0) | (p.stats ? 2 : 0)) {
     case 0: return launch_conv_ring2_k<T, CK, NT, 0>(p, st);
     case 1: return launch_conv_ring2_k<T, CK, NT, 1>(p, st);

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SEGMI_BF16, SEGMI_F32, Act, InAffine, check, lib
+from ._lib import SEGMI_BF16, SEGMI_F32, Act, BnBwdSums, InAffine, check, lib
 
 _DT = {torch.float32: SEGMI_F32, torch.bfloat16: SEGMI_BF16}
 
@@ -151,15 +151,29 @@ def conv3d_in_affine_ok(x, y, ksize, stride) -> bool:
     return bool(lib.segmi_conv3d_in_affine_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
 
 
+def conv3d_bn_bwd_sums_ok(x, y, ksize, stride) -> bool:
+    ax, ay = act(x), act(y)
+    return bool(lib.segmi_conv3d_bn_bwd_sums_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
+
+
 def conv3d_fwd(x, y, packed, w_src, w_kind, bias, ksize, stride, prelu_alpha=None,
-               residual=None, stats=None, in_tf=None) -> None:
+               residual=None, stats=None, in_tf=None, bn_bwd=None) -> None:
     """``in_tf`` = (scale, shift, alpha): the producer's BatchNorm-apply + PReLU is applied to ``x``
-    while it is staged (segmi_in_affine; only where ``conv3d_in_affine_ok``)."""
+    while it is staged (segmi_in_affine; only where ``conv3d_in_affine_ok``).
+    ``bn_bwd`` = (x_raw, mean, invstd, gamma, beta, alpha | None, partials): this launch is an
+    input-gradient conv whose output flows into that BatchNorm + PReLU; its epilogue also writes the
+    partial rows of the BatchNorm-backward reduction (segmi_bn_bwd_sums; where ``conv3d_bn_bwd_sums_ok``)."""
     ax, ay = act(x), act(y)
     ar = act(residual) if residual is not None else None
+    bb = None
+    if bn_bwd is not None:
+        xr, mean, invstd, gamma, beta, alpha, part = bn_bwd
+        abx = act(xr)
+        bb = C.byref(BnBwdSums(C.pointer(abx), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha),
+                               _ptr(part)))
     check(lib.segmi_conv3d_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed),
                                _ptr(w_src), w_kind, _ptr(bias), _ptr(prelu_alpha), _ref(ar),
-                               _ptr(stats), ksize, stride, _in_affine(in_tf), _stream()), "conv3d_fwd")
+                               _ptr(stats), ksize, stride, _in_affine(in_tf), bb, _stream()), "conv3d_fwd")
 
 
 def conv3d_pair_ok(x, y_a, y_b) -> bool:

@@ -626,8 +626,24 @@ class UNetEngine:
                 self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw,
                             conv.gb if need_bias else None, conv.k, conv.stride, ws, in_tf=in_tf)
 
-    def _dgrad(self, conv: _Conv, dy, dx, residual=None):
-        """dx = dgrad(conv, dy) (+ residual)."""
+    def _bsum_ok(self, conv: _Conv, dy, dx, bn: Optional["_BN"]) -> bool:
+        """the BatchNorm-backward reduction of `bn` (whose output gradient is dx = dgrad(conv, dy)) can
+        run in that input-gradient launch's epilogue (segmi_bn_bwd_sums)"""
+        return (bn is not None and self.fuse_bn_bwd and self.dtype == torch.bfloat16 and self.dropout_p <= 0.0
+                and not conv.transposed and conv.stride == 1 and conv.k == 3 and conv.mfma
+                and ops.conv3d_bn_bwd_sums_ok(dy, dx, 3, 1))
+
+    def _dgrad(self, conv: _Conv, dy, dx, residual=None, bsum=None):
+        """dx = dgrad(conv, dy) (+ residual).  ``bsum`` = (bn, x_raw): also the partial rows of that
+        BatchNorm's backward reduction over (dx, x_raw); returns their row count (else 0)."""
+        if bsum is not None:
+            bn, x_raw = bsum
+            rows = ops.conv3d_stats_rows(dy, dx, conv.k, 1)
+            part = self._fstat(rows, bn.c)
+            self._timed(conv.prefix + ":dgrad", ops.conv3d_fwd, dy, dx, conv.dgrad_pack(), conv.w, 1,
+                        None, conv.k, 1, residual=residual,
+                        bn_bwd=(x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part))
+            return rows
         if conv.transposed:
             ops.conv3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, 0, None, 3, 2, residual=residual)
         elif conv.stride == 2:
@@ -636,12 +652,18 @@ class UNetEngine:
             self._timed(conv.prefix + ":dgrad", ops.conv3d_fwd, dy, dx, conv.dgrad_pack(), conv.w, 1,
                         None, conv.k, 1, residual=residual)
 
-    def _bn_bwd(self, bn: _BN, dy, x_raw, dx):
-        rows = ops.bn_act_bwd_rows(x_raw)
-        part = self._fstat(rows, bn.c)
+    def _bn_bwd(self, bn: _BN, dy, x_raw, dx, sums_rows: int = 0):
+        """``sums_rows`` > 0: the reduction's partial rows were written by the launch that produced dy
+        (``_dgrad(..., bsum=)``); only finalisation and apply remain"""
         count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
-        ops.bn_act_bwd_reduce(dy, x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part,
-                              dropout=bn.drop())
+        if sums_rows:
+            rows = sums_rows
+            part = self._fstat(rows, bn.c)
+        else:
+            rows = ops.bn_act_bwd_rows(x_raw)
+            part = self._fstat(rows, bn.c)
+            ops.bn_act_bwd_reduce(dy, x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part,
+                                  dropout=bn.drop())
         ops.bn_act_bwd_finalize(part, rows, bn.c, count, bn.gamma, bn.invstd, bn.g_gamma,
                                 bn.g_beta, bn.g_alpha, bn.coef)
         ops.bn_act_bwd_apply(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
@@ -724,9 +746,12 @@ class UNetEngine:
                     cur = a
         self._saved[pre] = saved
 
-    def _ru_bwd(self, ru, dout, dx=None, extra=None):
+    def _ru_bwd(self, ru, dout, dx=None, extra=None, dx_bn=None):
         """Backward of a residual unit.  dout: grad of its output.  If dx is given it receives
-        the input gradient (+ `extra`, an additional gradient flowing into the same input)."""
+        the input gradient (+ `extra`, an additional gradient flowing into the same input).
+        ``dx_bn`` = (bn, x_raw): dx is the output gradient of that BatchNorm; when the unit's last
+        launch into dx can carry the reduction of its backward, the partial-row count is returned
+        (else 0)."""
         pre = ru["prefix"]
         sv = self._saved[pre]
         x = sv["x"]
@@ -740,20 +765,26 @@ class UNetEngine:
             with torch.cuda.stream(br) if br is not None else _NullCtx():
                 self._dgrad(rc, dout, dx, residual=extra)
         g = dout            # gradient flowing back through the conv branch
+        g_rows = 0          # > 0: the launch that wrote g also wrote the next BatchNorm's reduction rows
         for i in range(nun - 1, -1, -1):
             conv, bn = ru["units"][i]
             xin = sv[f"in{i}"]
             if bn is not None:
                 r = sv[f"r{i}"]
                 dr = self._buf(f"{pre}.dr{i}", r.shape)
-                self._bn_bwd(bn, g, r, dr)
+                self._bn_bwd(bn, g, r, dr, sums_rows=g_rows)
             else:
                 dr = g
+            g_rows = 0
             self._wgrad(conv, xin, dr, need_bias=bn is None and conv is not self._top_bias_conv,
                         in_tf=sv.get(f"tf{i}"))
             if i > 0:
                 da = self._buf(f"{pre}.da{i - 1}", xin.shape)
-                self._dgrad(conv, dr, da)
+                pbn = ru["units"][i - 1][1]
+                if self._bsum_ok(conv, dr, da, pbn):
+                    g_rows = self._dgrad(conv, dr, da, bsum=(pbn, sv[f"r{i - 1}"]))
+                else:
+                    self._dgrad(conv, dr, da)
                 g = da
             else:
                 first_dr = dr
@@ -762,18 +793,17 @@ class UNetEngine:
         # every parameter gradient of this unit (and of everything after it in the arena) is final
         self._grads_ready(self.param_offsets[f"model.{pre}.conv.unit0.conv.weight"][0])
         if dx is None:
-            return
+            return 0
         conv0 = ru["units"][0][0]
+        bsum = dx_bn if dx_bn is not None and self._bsum_ok(conv0, first_dr, dx, dx_bn[0]) else None
         if rc is not None:
             self._join_branch(br)
-            self._dgrad(conv0, first_dr, dx, residual=dx)
-        else:
-            # identity residual: dx = dgrad(conv0) + dout (+ extra)
-            if extra is not None:
-                ops.add(dout, extra, dx)
-                self._dgrad(conv0, first_dr, dx, residual=dx)
-            else:
-                self._dgrad(conv0, first_dr, dx, residual=dout)
+            return self._dgrad(conv0, first_dr, dx, residual=dx, bsum=bsum) or 0
+        # identity residual: dx = dgrad(conv0) + dout (+ extra)
+        if extra is not None:
+            ops.add(dout, extra, dx)
+            return self._dgrad(conv0, first_dr, dx, residual=dx, bsum=bsum) or 0
+        return self._dgrad(conv0, first_dr, dx, residual=dout, bsum=bsum) or 0
 
     def _ru_fwd_eval(self, ru, x, out):
         pre = ru["prefix"]
@@ -873,9 +903,9 @@ class UNetEngine:
         cat, u = sv["cat"], sv["u"]
         c = lvl["c"]
         dau = self._buf(f"{p}dau", u.shape)
-        self._ru_bwd(lvl["upru"], dout, dx=dau)
+        rows = self._ru_bwd(lvl["upru"], dout, dx=dau, dx_bn=(lvl["upbn"], u))
         du = self._buf(f"{p}du", u.shape)
-        self._bn_bwd(lvl["upbn"], dau, u, du)
+        self._bn_bwd(lvl["upbn"], dau, u, du, sums_rows=rows)
         up = lvl["upconv"]
         self._wgrad(up, cat, du, need_bias=False)
         self._grads_ready(self.param_offsets[f"model.{p}2.0.conv.weight"][0])
@@ -1032,6 +1062,9 @@ class UNetEngine:
     # BatchNorm-apply + PReLU folded into the consumer conv's staging where the kernels allow it
     # (segmi_in_affine); SEGMI_FUSE_BN=0 keeps the separate pass for A/B measurements
     fuse_bn_apply = os.environ.get("SEGMI_FUSE_BN", "1") != "0"
+    # BatchNorm-backward reduction in the epilogue of the input-gradient launch that produces its
+    # operand (segmi_bn_bwd_sums); SEGMI_FUSE_BN_BWD=0 keeps the separate two-tensor pass (A/B)
+    fuse_bn_bwd = os.environ.get("SEGMI_FUSE_BN_BWD", "1") != "0"
     _side2 = None
 
     def _fork_branch(self):

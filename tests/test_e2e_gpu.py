@@ -658,3 +658,30 @@ def test_dice_loss_refuses_more_than_64_classes_loudly():
         DiceLoss(to_onehot_y=True, softmax=True)(lg, lab)
     ok = DiceLoss(to_onehot_y=True, softmax=True)(lg[:, :64].contiguous(), lab)
     assert bool(torch.isfinite(ok))
+
+
+def test_bn_backward_sums_fused_into_input_gradient_launches_match_the_separate_pass():
+    """SEGMI_FUSE_BN_BWD (segmi_bn_bwd_sums): logits, loss and stored activation gradients are
+    bit-identical, parameter gradients agree to f32 summation order."""
+    from segmantic_amd.seg.unet import UNetEngine
+    img, lab = synthetic_batch(2, 64, 16, seed=11)
+    grads = {}
+    for flag in (False, True):
+        UNetEngine.fuse_bn_bwd = flag
+        try:
+            _, net = pair(16, (16, 32, 64), (2, 2))
+            net.mixed_precision = True
+            net.train()
+            res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+            torch.cuda.synchronize()
+            eng = net._engine
+            grads[flag] = (eng.flat_grad.clone(), float(res["loss"].cpu()), eng._bufs["du"].clone())
+        finally:
+            UNetEngine.fuse_bn_bwd = True
+    (ga, la, dua), (gb, lb, dub) = grads[False], grads[True]
+    assert la == lb
+    # du = BatchNorm-backward apply of the top level: depends on the fused sums through coef only
+    assert float((dua.float() - dub.float()).abs().max()) <= 2e-2 * float(dua.float().abs().max())
+    assert float((ga - gb).abs().max()) < 2e-3 * float(ga.abs().max())
+    # (a coef that differs in its last bits flips bf16 roundings of du, which every later gradient sees)
+    assert float((ga - gb).abs().mean()) < 2e-3 * float(ga.abs().mean()) + 1e-9

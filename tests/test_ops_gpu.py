@@ -1005,3 +1005,62 @@ def test_confusion_matrix_metric_and_empty_dice_aggregate_match_monai_rule():
     assert bool(torch.isnan(d).all())
     assert float(dm.aggregate()) == 0.0
     assert float(ref_dice_metric(pred[:1, :, :4, :4, :4], zeros, K)[1]) == 0.0
+
+
+@pytest.mark.parametrize("shape,residual", [((2, 32, 64, 128), "in"), ((2, 33, 60, 120), "other"), ((4, 16, 64, 128), None)])
+def test_bn_bwd_sums_in_the_input_gradient_epilogue_match_the_separate_pass(shape, residual):
+    """segmi_bn_bwd_sums: the ring kernel's input-gradient launch also writes the partial rows of the
+    BatchNorm-backward reduction over (its own stored output, x_raw).  Same dx bits; dgamma / dbeta /
+    dalpha / coef equal to the separate two-tensor pass up to f32 summation order."""
+    n, d, h, w = shape
+    c = 16
+    dy = rnd((n, c, d, h, w), 401, 0.5)
+    xr = rnd((n, c, d, h, w), 402, 2.0) + 0.3
+    wt = rnd((c, c, 3, 3, 3), 403, 0.08)
+    dyd, xd = to_ndhwc(dy, torch.bfloat16), to_ndhwc(xr, torch.bfloat16)
+    pk = ops.wpack(torch.bfloat16, 1, wt.to(DEV), c, c, 3)
+    assert ops.conv3d_bn_bwd_sums_ok(dyd, dyd, 3, 1) and ops.conv3d_in_affine_ok(dyd, dyd, 3, 1)
+    mean = (rnd((c,), 404) * 0.5).to(DEV)
+    invstd = (rnd((c,), 405).abs() + 0.5).to(DEV)
+    gamma = (rnd((c,), 406) + 1.5).to(DEV)
+    beta = (rnd((c,), 407) * 0.3).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV)
+    res = {"in": dyd, "other": to_ndhwc(rnd((n, c, d, h, w), 408), torch.bfloat16), None: None}[residual]
+    count = n * d * h * w
+
+    def finalize(part, rows):
+        dg, db, da = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(1, device=DEV)
+        coef = torch.empty((2, c), device=DEV)
+        ops.bn_act_bwd_finalize(part, rows, c, count, gamma, invstd, dg, db, da, coef)
+        torch.cuda.synchronize()
+        return dg.cpu(), db.cpu(), da.cpu(), coef.cpu()
+
+    dx_a = torch.empty_like(dyd)
+    ops.conv3d_fwd(dyd, dx_a, pk, None, 1, None, 3, 1, residual=res)
+    rows_a = ops.bn_act_bwd_rows(xd)
+    part_a = torch.empty((rows_a, 3, c), device=DEV)
+    ops.bn_act_bwd_reduce(dx_a, xd, mean, invstd, gamma, beta, alpha, part_a)
+    ref = finalize(part_a, rows_a)
+
+    dx_b = torch.empty_like(dyd)
+    rows_b = ops.conv3d_stats_rows(dyd, dx_b, 3, 1)
+    part_b = torch.full((rows_b, 3, c), float("nan"), device=DEV)
+    ops.conv3d_fwd(dyd, dx_b, pk, None, 1, None, 3, 1, residual=res,
+                   bn_bwd=(xd, mean, invstd, gamma, beta, alpha, part_b))
+    got = finalize(part_b, rows_b)
+    assert torch.equal(dx_a, dx_b)
+    for a, b, name in zip(ref, got, ("dgamma", "dbeta", "dalpha", "coef")):
+        scale = float(a.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) < 2e-4 * scale + 1e-3 * float(a.abs().mean()), name
+    # no PReLU (alpha = None): the third sum is unused, dz = g
+    part_c = torch.empty((rows_b, 3, c), device=DEV)
+    ops.conv3d_fwd(dyd, dx_b, pk, None, 1, None, 3, 1, residual=res,
+                   bn_bwd=(xd, mean, invstd, gamma, beta, None, part_c))
+    ops.bn_act_bwd_reduce(dx_a, xd, mean, invstd, gamma, beta, None, part_a)
+    dg = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV); coef = torch.empty((2, c), device=DEV)
+    ops.bn_act_bwd_finalize(part_a, rows_a, c, count, gamma, invstd, dg, db, None, coef)
+    dg2 = torch.empty(c, device=DEV); db2 = torch.empty(c, device=DEV); coef2 = torch.empty((2, c), device=DEV)
+    ops.bn_act_bwd_finalize(part_c, rows_b, c, count, gamma, invstd, dg2, db2, None, coef2)
+    torch.cuda.synchronize()
+    assert float((dg - dg2).abs().max()) < 2e-4 * float(dg.abs().max()) + 1e-3 * float(dg.abs().mean())
+    assert float((db - db2).abs().max()) < 2e-4 * float(db.abs().max()) + 1e-3 * float(db.abs().mean())
