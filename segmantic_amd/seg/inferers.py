@@ -190,10 +190,11 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     outs, labs, cnts = [], [], []
     lanes = _lane_streams(dev) if into is not None else None
     # Window groups handed to OUR network may be larger than sw_batch_size: in eval mode every
-    # window is computed independently of its batch neighbours (folded BatchNorm; bit-identical
-    # whatever the grouping -- tests/test_e2e_gpu.py), and the deep 8^3 / 16^3 layers of a 4-window
-    # forward do not fill the chip (47 us per launch for 3 % of the FLOPs).  A foreign predictor
-    # callable always sees exactly sw_batch_size windows, as MONAI would give it.
+    # window is computed independently of its batch neighbours (folded BatchNorm: the grouping can
+    # only change which kernel a layer picks, i.e. the f32 summation order in front of a bf16
+    # rounding), and the deep 8^3 / 16^3 layers of a 4-window forward do not fill the chip (47 us
+    # per launch for 3 % of the FLOPs).  A foreign predictor callable always sees exactly
+    # sw_batch_size windows, as MONAI would give it.
     if into is not None:
         sw_batch_size = int(sw_batch_size) * group_factor()
     for b in range(B):

@@ -596,10 +596,15 @@ def test_full_size_c3_512_sliding_window_bf16():
     assert torch.equal(lab_d, s.labels)                      # deferred == streaming, bit for bit
     assert torch.equal(lab_d[0, 0].long(), torch.argmax(s.logits[0], 0))
     assert int(lab_d.long().unique().numel()) > 1
-    # one window on its own equals the plain forward of that block (interior overlap excluded)
+    # where only window 0 contributes, the volume result is the plain forward of that block.  Not
+    # bit for bit: a 16-window group and a single patch pick different kernels for some layers
+    # (the z-marching ring needs >= 256 columns), i.e. another f32 summation order before the bf16
+    # roundings -- the values agree to bf16 resolution
     with torch.no_grad():
         y = net(vol[:, :, :128, :128, :128].contiguous()).float()
-    assert torch.equal(s.logits[0, :, :64, :64, :64], y[0, :, :64, :64, :64])
+    a, b = s.logits[0, :, :64, :64, :64], y[0, :, :64, :64, :64]
+    assert float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
+    assert float((a - b).abs().mean()) <= 2.0 ** -9 * float(b.abs().mean())
 
 
 def test_full_size_c4_160_k32_training_step_bf16():
