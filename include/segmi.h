@@ -127,6 +127,17 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
                      const float* prelu_alpha, const segmi_act* residual,
                      float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
                      const segmi_bn_bwd_sums* bn_bwd /* nullable */, void* stream);
+/* Inference, full-resolution decoder of monai UNet as ONE launch (csrc/dectop.hip):
+ *   h = PReLU(ConvTranspose3d(k3, s2, p1, op1; 32 -> 16)(in) with BatchNorm folded), out = Conv3d(k3; 16 -> 16)(h) + bias + h
+ * i.e. `up` layer "model.2.0" followed by the conv-only ResidualUnit "model.2.1" (monai_unet.py:114-124), whose
+ * 16-channel intermediate then never reaches HBM.  Bit-identical to segmi_convT3d_fwd + segmi_conv3d_fwd.
+ * up_frag: bf16 [27][64][8]: tap (kd*3+kh)*3+kw, lane (g, co), W_T[ci = 8g .. 8g+7][co][tap] * bn_scale[co];
+ * up_bias: f32[16] folded bias; up_alpha: PReLU slope; conv_packed: kind-0 segmi_wpack of the 16 -> 16 conv.
+ * segmi_dectop_ok(): bf16, in [N,D,H,W,32], out [N,2D,2H,2W,16] with 2D % 4 == 0, 2H % 16 == 0, 2W % 16 == 0. */
+int segmi_dectop_ok(int dtype, const segmi_act* in, const segmi_act* out);
+int segmi_dectop_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* up_frag,
+                     const float* up_bias, const float* up_alpha, const void* conv_packed,
+                     const float* conv_bias, void* stream);
 /* The first ResidualUnit of the network convolves its (<= 4 channel) input twice with the same
  * geometry: subunit 0 (k3, stride s) and the residual convolution (k3, stride s).  One launch
  * stages the input once and produces both:  out_a = prelu_a(conv_a(in) + bias_a) with optional

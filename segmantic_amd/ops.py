@@ -176,6 +176,26 @@ def conv3d_fwd(x, y, packed, w_src, w_kind, bias, ksize, stride, prelu_alpha=Non
                                _ptr(stats), ksize, stride, _in_affine(in_tf), bb, _stream()), "conv3d_fwd")
 
 
+def dectop_ok(x, y) -> bool:
+    ax, ay = act(x), act(y)
+    return bool(lib.segmi_dectop_ok(dtype_code(x), C.byref(ax), C.byref(ay)))
+
+
+def dectop_up_frag(w_t: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """A-operand fragments of the transposed conv for ``segmi_dectop_fwd``: w_t [32, 16, 3, 3, 3] f32
+    (torch ConvTranspose3d layout), scale f32[16] (folded BatchNorm) -> bf16 [27, 64, 8]."""
+    ws = (w_t * scale.view(1, -1, 1, 1, 1)).reshape(32, 16, 27)
+    return ws.permute(2, 0, 1).reshape(27, 4, 8, 16).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).reshape(27, 64, 8)
+
+
+def dectop_fwd(x, y, up_frag, up_bias, up_alpha, conv_packed, conv_bias) -> None:
+    """inference: ConvTranspose3d(32 -> 16) + folded BN + PReLU, then conv(16 -> 16) + identity residual,
+    one launch (segmi_dectop_fwd)"""
+    ax, ay = act(x), act(y)
+    check(lib.segmi_dectop_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(up_frag), _ptr(up_bias),
+                               _ptr(up_alpha), _ptr(conv_packed), _ptr(conv_bias), _stream()), "dectop_fwd")
+
+
 def conv3d_pair_ok(x, y_a, y_b) -> bool:
     ax, aa, ab = act(x), act(y_a), act(y_b)
     return bool(lib.segmi_conv3d_pair_ok(dtype_code(x), C.byref(ax), C.byref(aa), C.byref(ab)))

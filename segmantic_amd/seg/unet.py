@@ -550,6 +550,11 @@ class UNetEngine:
                 and ops.conv3d_in_affine_ok(x, y, 3, 1))
 
     merge_eval_pairs = os.environ.get("SEGMI_MERGE_PAIRS", "1") != "0"
+    # inference: transposed conv + conv-only unit of the full-resolution decoder as one launch
+    # (csrc/dectop.hip).  OFF by default: bit-identical to the two launches but not faster yet --
+    # 69 vs 59 us per 128^3 patch, 19.6 vs 20.4 volumes/s: its producer waves spend ~2000 instructions
+    # per step on 9-of-16-lane tiles; SEGMI_FUSE_EVAL_TOP=1 selects it.
+    fuse_eval_top = os.environ.get("SEGMI_FUSE_EVAL_TOP", "0") == "1"
 
     def _merged_eval(self, ru, x, oshape):
         """(pack, bias, buffer) of the merged subunit-0 + residual convolution of a unit (inference,
@@ -891,8 +896,21 @@ class UNetEngine:
                 self._saved[p + "up"] = {"cat": cat, "u": u}
                 self._ru_fwd_train(upru, au, out)
         else:
-            au = self._buf(f"{p}au.e", oshape)
             sc, sh = ubn.eval_affine()
+            upru = lvl["upru"]
+            conv0, bn0 = upru["units"][0]
+            if (self.fuse_eval_top and lvl["is_top"] and self.dtype == torch.bfloat16 and bn0 is None
+                    and upru["res"] is None and up.cin == 32 and up.cout == 16 and conv0.cin == conv0.cout == 16
+                    and ops.dectop_ok(cat, out)):
+                # the full-resolution decoder as ONE launch: the 16-channel tensor between the
+                # transposed conv and the conv-only unit never reaches HBM (csrc/dectop.hip)
+                hit = lvl.get("_dectop")
+                if hit is None or hit[0] != self.weights_version:
+                    hit = (self.weights_version, ops.dectop_up_frag(up.w, sc), torch.addcmul(sh, up.b, sc))
+                    lvl["_dectop"] = hit
+                ops.dectop_fwd(cat, out, hit[1], hit[2], ubn.alpha, conv0.fwd_pack(), conv0.b)
+                return
+            au = self._buf(f"{p}au.e", oshape)
             pack, wsrc, bias = up.folded(sc, sh)
             ops.convT3d_fwd(cat, au, pack, wsrc, bias, prelu_alpha=ubn.alpha)
             self._ru_fwd_eval(lvl["upru"], au, out)

@@ -690,3 +690,26 @@ def test_bn_backward_sums_fused_into_input_gradient_launches_match_the_separate_
     assert float((ga - gb).abs().max()) < 2e-3 * float(ga.abs().max())
     # (a coef that differs in its last bits flips bf16 roundings of du, which every later gradient sees)
     assert float((ga - gb).abs().mean()) < 2e-3 * float(ga.abs().mean()) + 1e-9
+
+
+def test_fused_eval_decoder_top_is_bit_identical_and_used_by_the_sliding_window():
+    from segmantic_amd.seg.unet import UNetEngine
+    _, net = pair(16, (16, 32, 64), (2, 2))
+    net.eval()
+    net.mixed_precision = True
+    img, _ = synthetic_batch(2, 64, 16, seed=13)
+    img = img.to(DEV)
+    outs = {}
+    for flag in (False, True):
+        UNetEngine.fuse_eval_top = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = net(img).float().clone()
+                sw = sliding_window_inference(img[:1], (32, 32, 32), 4, net, 0.5, return_labels=True)
+                outs[(flag, "sw")] = (sw.logits.clone(), sw.labels.clone())
+        finally:
+            UNetEngine.fuse_eval_top = False     # the default (the fused launch is opt-in: not faster yet)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[False], outs[True])
+    assert torch.equal(outs[(False, "sw")][0], outs[(True, "sw")][0])
+    assert torch.equal(outs[(False, "sw")][1], outs[(True, "sw")][1])

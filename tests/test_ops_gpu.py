@@ -1064,3 +1064,42 @@ def test_bn_bwd_sums_in_the_input_gradient_epilogue_match_the_separate_pass(shap
     torch.cuda.synchronize()
     assert float((dg - dg2).abs().max()) < 2e-4 * float(dg.abs().max()) + 1e-3 * float(dg.abs().mean())
     assert float((db - db2).abs().max()) < 2e-4 * float(db.abs().max()) + 1e-3 * float(db.abs().mean())
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 16, 24, 32), (3, 6, 8, 40)])
+def test_fused_full_resolution_decoder_is_bit_identical_to_the_two_launches(shape):
+    """segmi_dectop_fwd: ConvTranspose3d(32 -> 16) + folded BN + PReLU -> conv(16 -> 16) + identity
+    residual in one launch; same tap order and k-slot layout as the separate kernels => same bits."""
+    n, d, h, w = shape
+    x = to_ndhwc(rnd((n, 32, d, h, w), 501), torch.bfloat16)
+    wt = (rnd((32, 16, 3, 3, 3), 502, 0.06)).to(DEV)          # ConvTranspose3d layout [Cin, Cout, 3,3,3]
+    wc = (rnd((16, 16, 3, 3, 3), 503, 0.08)).to(DEV)
+    scale = (rnd((16,), 504).abs() + 0.5).to(DEV)
+    ub = (rnd((16,), 505) * 0.2).to(DEV)
+    cb = (rnd((16,), 506) * 0.2).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV)
+    fine = (n, 2 * d, 2 * h, 2 * w, 16)
+    # two launches
+    up_pack = ops.wpack(torch.bfloat16, 2, wt, 32, 16, 3, scale=scale)
+    cv_pack = ops.wpack(torch.bfloat16, 0, wc, 16, 16, 3)
+    hmid = torch.empty(fine, dtype=torch.bfloat16, device=DEV)
+    ops.convT3d_fwd(x, hmid, up_pack, None, ub, prelu_alpha=alpha)
+    ref = torch.empty_like(hmid)
+    ops.conv3d_fwd(hmid, ref, cv_pack, None, 0, cb, 3, 1, residual=hmid)
+    # one launch
+    out = torch.full(fine, float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert ops.dectop_ok(x, out)
+    ops.dectop_fwd(x, out, ops.dectop_up_frag(wt, scale), ub, alpha, cv_pack, cb)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    assert torch.equal(out, ref), f"max diff {float((out.float() - ref.float()).abs().max())}"
+    # independent check of the pair against torch (oracle semantics), bf16 tolerance
+    xr = from_ndhwc(x)
+    hq = F.prelu(F.conv_transpose3d(xr, q(wt.cpu() * scale.cpu().view(1, -1, 1, 1, 1), torch.bfloat16), ub.cpu(),
+                                    stride=2, padding=1, output_padding=1), alpha.cpu())
+    hq = q(hq, torch.bfloat16)
+    want = F.conv3d(hq, q(wc.cpu(), torch.bfloat16), cb.cpu(), padding=1) + hq
+    assert relerr(from_ndhwc(out), want) < BF16_RTOL
+    # shapes the kernel does not take are refused by the query
+    bad = torch.empty((n, 2 * d, 2 * h + 2, 2 * w, 16), dtype=torch.bfloat16, device=DEV)
+    assert not ops.dectop_ok(x, bad)
