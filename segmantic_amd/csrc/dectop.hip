@@ -200,16 +200,22 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
   const int lane_a = lane * 16;                       // A fragment of a tap
   const int lane_w = (2 * r) * ROWB + 8 * g;          // ring row: footprint column 2r (+1), channels 4g ..
   // fine plane fz, footprint row j: taps of one parity combination (NZ z-taps x NY y-taps), both x parities
+  // (an emit is the producers' unit of overhead: 144 per step and workgroup, so it is branch-free: PReLU as
+  // fma(alpha, min(v, 0), max(v, 0)) -- the same bits as the select form for any slope -- and the x-range
+  // test as a per-lane AND mask computed once)
+  const unsigned xmask0 = (unsigned)(ox0 + 2 * r) < (unsigned)p.Wo ? 0xffffffffu : 0u;       // px = 0: fine x = ox0 + 2r
+  const unsigned xmask1 = (unsigned)(ox0 + 2 * r - 1) < (unsigned)p.Wo ? 0xffffffffu : 0u;   // px = 1: fine x = ox0 - 1 + 2r
   auto emit = [&](char* dst, f32x4 acc, int px, bool row_in) {
-    // px = 0: fine x = ox0 + 2r (footprint column 2r + 1); px = 1: fine x = ox0 - 1 + 2r (column 2r)
-    const int fx = ox0 + 2 * r - px;
-    f32x4 v = acc + ubias;
+    // px = 0: footprint column 2r + 1; px = 1: column 2r
+    u32x2 o = u32x2{0u, 0u};
+    if (row_in) {
+      f32x4 v = acc + ubias;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : ualpha * v[e];
-    const bool in = row_in && (unsigned)fx < (unsigned)p.Wo;
-    u32x2 o;
-    o[0] = in ? pack_bf16x2(v[0], v[1]) : 0u;
-    o[1] = in ? pack_bf16x2(v[2], v[3]) : 0u;
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(ualpha, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
+      const unsigned m = px ? xmask1 : xmask0;
+      o[0] = pack_bf16x2(v[0], v[1]) & m;
+      o[1] = pack_bf16x2(v[2], v[3]) & m;
+    }
     if (r <= TW / 2) *reinterpret_cast<u32x2*>(dst + lane_w + (1 - px) * ROWB) = o;
   };
   // One fine plane, the rows j0, j0 + 8, j0 + 16 of this wave (all of one y-parity: NY y-taps), NZ
@@ -320,8 +326,7 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
       ws_barrier();                                    // X: the coarse planes are in LDS
       if (more) {
         if (step + 2 < nsteps_z) cat_fetch2((a + 4 + 1) >> 1);
-        produce(a, 4, 2 * pw);
-        produce(a, 4, 2 * pw + 1);
+        for (int vw = 2 * pw; vw < 2 * pw + 2; ++vw) produce(a, 4, vw);
       }
       ws_barrier();                                    // Y: ring planes of step s + 1 complete, step s consumed
     }
