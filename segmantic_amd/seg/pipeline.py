@@ -3,7 +3,7 @@
 Restates the reference's ``default_preprocessing`` (``src/segmantic/seg/monai_unet.py:151-176``)
 and the predict-time inversion chain (``:612-625``) without MONAI:
 
-  load (NIfTI, channel first, MONAI axis order [C, x, y, z])  -> Orientation("RAS")
+  load (NIfTI / MetaImage / NRRD, channel first, MONAI axis order [C, x, y, z])  -> Orientation("RAS")
   -> NormalizeIntensity(channel_wise)   [HIP kernel]          -> CropForeground(source > 0)
   -> float32                            -> optional Spacing(pixdim)  [HIP trilinear resample]
 
@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..data.nifti import read_nifti, write_nifti
+from ..data.imageio import read_image, strip_image_suffix, write_image
 
 
 # ---------------------------------------------------------------------------- orientation
@@ -145,7 +145,7 @@ class PredictPipeline:
 
     # -- forward chain ----------------------------------------------------------------------
     def _load(self, path) -> tuple:
-        arr, A = read_nifti(path)
+        arr, A = read_image(path)
         if arr.ndim == 3:
             vol = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 1, 0)))[None]   # [1,x,y,z]
         else:
@@ -210,9 +210,8 @@ class PredictPipeline:
         return lab
 
     def save(self, label_vol: torch.Tensor, item: Dict, output_dir: Path) -> Path:
-        name = item["path"].name
-        stem = name[:-7] if name.endswith(".nii.gz") else Path(name).stem
-        out = Path(output_dir) / f"{stem}.nii.gz"
+        # MONAI SaveImaged(output_postfix="", separate_folder=False): <stem>.nii.gz (the default output_ext)
+        out = Path(output_dir) / f"{strip_image_suffix(item['path'].name)}.nii.gz"
         arr = label_vol.cpu().numpy().transpose(2, 1, 0)            # [z,y,x]
-        write_nifti(out, arr, item["affine0"])
+        write_image(out, arr, item["affine0"])
         return out

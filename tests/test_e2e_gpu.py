@@ -713,3 +713,61 @@ def test_fused_eval_decoder_top_is_bit_identical_and_used_by_the_sliding_window(
     assert torch.equal(outs[False], outs[True])
     assert torch.equal(outs[(False, "sw")][0], outs[(True, "sw")][0])
     assert torch.equal(outs[(False, "sw")][1], outs[(True, "sw")][1])
+
+
+def test_train_config_with_bundle_dictionaries_adabelief_and_mixed_image_formats(tmp_path):
+    """The `preprocessing` / `augmentation` keys of the config schema as MONAI-bundle dictionaries
+    (reference monai_unet.py:232-262), AdaBelief + cosine schedule (:305-337), MetaImage / NRRD inputs,
+    `predict --spacing`: the run trains, checkpoints, predicts on the source grid."""
+    import yaml
+    from typer.testing import CliRunner
+
+    from segmantic_amd.commands.monai_unet_cli import app
+    from segmantic_amd.data.imageio import read_image, write_image
+    datalist = _write_dataset(tmp_path / "data", n=4, size=24)
+    root = datalist.parent
+    # re-write two volumes as MetaImage / NRRD with an LPS-flipped, anisotropic geometry
+    dl = json.loads(datalist.read_text())
+    A = np.array([[-1.0, 0, 0, 10.0], [0, -1.0, 0, 20.0], [0, 0, 1.5, -5.0], [0, 0, 0, 1.0]])
+    for i, ext in ((0, ".mha"), (1, ".nrrd")):
+        for kind in ("image", "label"):
+            arr, _ = read_image(root / kind / f"c{i}.nii.gz")
+            write_image(root / kind / f"c{i}{ext}", arr, A)
+            (root / kind / f"c{i}.nii.gz").unlink()
+        dl["training"][i] = {"image": f"image/c{i}{ext}", "label": f"label/c{i}{ext}"}
+    datalist.write_text(json.dumps(dl))
+    keys = ["@image_key", "@label_key"]
+    cfg = {"datalist": str(datalist), "output_dir": str(tmp_path / "results"), "spatial_size": [16, 16, 16],
+           "channels": [16, 32, 64], "strides": [2, 2], "max_epochs": 2, "mixed_precision": True, "gpu_ids": [0],
+           "optimizer": {"optimizer": "AdaBelief", "lr": 1e-3, "epsilon": 1e-8, "weight_decouple": True},
+           "lr_scheduling": {"scheduler": "Cosine", "T_0": 2, "T_multi": 1},
+           "preprocessing": {"_target_": "Compose", "transforms": [
+               {"_target_": "LoadImaged", "keys": keys, "reader": "ITKReader", "ensure_channel_first": True},
+               {"_target_": "Orientationd", "keys": keys, "axcodes": "RAS"},
+               {"_target_": "NormalizeIntensityd", "keys": "@image_key", "channel_wise": True},
+               {"_target_": "CropForegroundd", "keys": keys, "source_key": "@label_key"},
+               {"_target_": "DataStatsd", "keys": "@image_key", "_disabled_": True},
+               {"_target_": "EnsureTyped", "keys": keys}]},
+           "augmentation": {"_target_": "Compose", "transforms": [
+               {"_target_": "SpatialPadd", "keys": keys, "spatial_size": [16, 16, 16]},
+               {"_target_": "RandCropByLabelClassesd", "keys": keys, "label_key": "@label_key",
+                "spatial_size": [16, 16, 16], "num_classes": 3, "num_samples": 3, "ratios": [0, 1, 1]},
+               {"_target_": "RandFlipd", "keys": keys, "prob": 0.5, "spatial_axis": 0}]}}
+    (tmp_path / "cfg.yml").write_text(yaml.safe_dump(cfg))
+    runner = CliRunner()
+    res = runner.invoke(app, ["train-config", "-c", str(tmp_path / "cfg.yml")])
+    assert res.exit_code == 0, (res.output, res.exception)
+    ckpts = sorted((tmp_path / "results").glob("epoch=*-val_loss=*-val_dice=*.ckpt"))
+    assert ckpts
+    res = runner.invoke(app, ["predict", "-d", str(root / "predict.json"), "-m", str(ckpts[-1]), "-r",
+                              str(tmp_path / "pred"), "--spacing", "1.5", "--spacing", "1.5", "--spacing", "1.5",
+                              "--gpu-ids", "0"])      # typer list option: repeated flag, as in the reference CLI
+    assert res.exit_code == 0, (res.output, res.exception)
+    assert "Total Conf. Matrix Metrics:" in res.output and "sensitivity" in res.output
+    pred, _ = read_image(tmp_path / "pred" / "c3.nii.gz")
+    assert pred.shape == (24, 24, 24) and pred.max() <= 2
+    # an unsupported transform in the dictionary is refused by name
+    cfg["augmentation"]["transforms"].append({"_target_": "RandGaussianNoised", "keys": "@image_key"})
+    (tmp_path / "bad.yml").write_text(yaml.safe_dump(cfg))
+    res = runner.invoke(app, ["train-config", "-c", str(tmp_path / "bad.yml")])
+    assert res.exit_code != 0 and "RandGaussianNoised" in str(res.exception)

@@ -356,3 +356,45 @@ def test_load_from_checkpoint_accepts_a_lightning_file_with_extra_entries(tmp_pa
     assert net.num_classes == 3 and net.spatial_size == [32, 32, 32]
     for k, v in src.state_dict().items():
         assert torch.equal(net.state_dict()[k], v), k
+
+
+def test_image_io_nifti_metaimage_nrrd_round_trip_and_lps_to_ras(tmp_path):
+    """LoadImaged(reader="ITKReader") reads any ITK format and hands MONAI a RAS affine (reference
+    monai_unet.py:157-162): MetaImage and NRRD store LPS geometry, NIfTI stores RAS."""
+    import numpy as np
+    from segmantic_amd.data.imageio import read_image, write_image
+    g = np.random.RandomState(0)
+    arr = (g.rand(5, 6, 7) * 100).astype(np.float32)
+    A = np.array([[0.0, -0.8, 0.0, 12.5], [1.1, 0.0, 0.0, -3.0], [0.0, 0.0, 2.5, 40.0], [0, 0, 0, 1.0]])
+    for name in ("v.nii.gz", "v.mha", "v.nrrd"):
+        write_image(tmp_path / name, arr, A)
+        back, A2 = read_image(tmp_path / name)
+        assert back.dtype == np.float32 and np.array_equal(back, arr), name
+        assert np.allclose(A2, A, atol=1e-5), name
+    lab = (g.rand(5, 6, 7) * 4).astype(np.uint8)
+    write_image(tmp_path / "l.nrrd", lab, A)
+    assert np.array_equal(read_image(tmp_path / "l.nrrd")[0], lab)
+    # a hand-written MetaImage header as ITK writes it (LPS: identity direction, offset (1, 2, 3), spacing .5 .6 .7)
+    data = np.arange(2 * 3 * 4, dtype=np.int16).reshape(4, 3, 2)
+    hdr = ("ObjectType = Image\nNDims = 3\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\n"
+           "TransformMatrix = 1 0 0 0 1 0 0 0 1\nOffset = 1 2 3\nCenterOfRotation = 0 0 0\nAnatomicalOrientation = RAI\n"
+           "ElementSpacing = 0.5 0.6 0.7\nDimSize = 2 3 4\nElementType = MET_SHORT\nElementDataFile = LOCAL\n")
+    (tmp_path / "itk.mha").write_bytes(hdr.encode() + data.tobytes())
+    arr2, A3 = read_image(tmp_path / "itk.mha")
+    assert np.array_equal(arr2, data)
+    assert np.allclose(A3, np.array([[-0.5, 0, 0, -1.0], [0, -0.6, 0, -2.0], [0, 0, 0.7, 3.0], [0, 0, 0, 1.0]]))
+    # external data file + zlib compression (.mhd)
+    import zlib
+    (tmp_path / "e.zraw").write_bytes(zlib.compress(data.tobytes()))
+    (tmp_path / "e.mhd").write_text(hdr.replace("CompressedData = False", "CompressedData = True")
+                                    .replace("ElementDataFile = LOCAL", "ElementDataFile = e.zraw"))
+    assert np.array_equal(read_image(tmp_path / "e.mhd")[0], data)
+    # NRRD header in RAS space, raw encoding
+    nh = ("NRRD0004\ntype: short\ndimension: 3\nspace: right-anterior-superior\nsizes: 2 3 4\n"
+          "space directions: (0.5,0,0) (0,0.6,0) (0,0,0.7)\nendian: little\nencoding: raw\nspace origin: (1,2,3)\n\n")
+    (tmp_path / "r.nrrd").write_bytes(nh.encode() + data.tobytes())
+    arr3, A4 = read_image(tmp_path / "r.nrrd")
+    assert np.array_equal(arr3, data) and np.allclose(A4, np.array([[0.5, 0, 0, 1], [0, 0.6, 0, 2], [0, 0, 0.7, 3], [0, 0, 0, 1.0]]))
+    import pytest
+    with pytest.raises(ValueError, match="unsupported image format"):
+        read_image(tmp_path / "x.png")
