@@ -335,7 +335,7 @@ def main():
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
     import torch.distributed as dist
 

@@ -26,12 +26,14 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SEGMI_DIST_BACKEND=gloo: rehearse the multi-process path where RCCL cannot run (several
+            # ranks sharing one GPU, CPU-only boxes); the product default on GPUs is nccl = RCCL
+            backend = os.environ.get("SEGMI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
