@@ -1103,3 +1103,40 @@ def test_fused_full_resolution_decoder_is_bit_identical_to_the_two_launches(shap
     # shapes the kernel does not take are refused by the query
     bad = torch.empty((n, 2 * d, 2 * h + 2, 2 * w, 16), dtype=torch.bfloat16, device=DEV)
     assert not ops.dectop_ok(x, bad)
+
+
+WS_WGRAD_CASES = [
+    # cin, cout, k, s, spatial of x (d,h,w), batch -- enough tiles (>= 4 per workgroup of the 256 / 128-wide grids)
+    # that the wave-specialised kernel takes the launch; ragged extents, volume borders in every dimension
+    (16, 16, 3, 1, (33, 60, 120), 2),      # row-split consumers, ragged z / y / x
+    (16, 32, 3, 1, (18, 64, 128), 4),      # 2 output-channel tiles share the X staging
+    (16, 32, 3, 2, (64, 64, 128), 2),      # stride 2 (the transposed-conv gradient of the decoder top)
+    (16, 64, 3, 2, (63, 66, 126), 2),      # stride 2, two output-channel chunks (grid.y = 2), ragged
+    (16, 16, 3, 2, (48, 80, 160), 2),      # stride 2, 16 x 16
+    (16, 16, 3, 1, (40, 64, 8), 8),        # narrow volumes: the 8-wide tile, tap-split consumers
+]
+
+
+@pytest.mark.parametrize("case", WS_WGRAD_CASES)
+def test_wave_specialised_wgrad_matches_torch(case):
+    cin, cout, k, s, sp, n = case
+    x = rnd((n, cin) + sp, 331)
+    osp = tuple((d + 2 - k) // s + 1 for d in sp)
+    dy = rnd((n, cout) + osp, 332)
+    w0 = torch.zeros((cout, cin, k, k, k), requires_grad=True)
+    b0 = torch.zeros((cout,), requires_grad=True)
+    F.conv3d(q(x, torch.bfloat16), w0, b0, stride=s, padding=1).backward(q(dy, torch.bfloat16))
+    xd, dyd = to_ndhwc(x, torch.bfloat16), to_ndhwc(dy, torch.bfloat16)
+    dw = torch.empty_like(w0, device=DEV)
+    db = torch.empty_like(b0, device=DEV)
+    ws = torch.empty(ops.conv3d_wgrad_workspace(xd, dyd, k, s), dtype=torch.uint8, device=DEV)
+    ops.conv3d_wgrad(xd, dyd, dw, db, k, s, ws)
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), w0.grad) < 5e-5
+    assert relerr(db.cpu(), b0.grad) < 5e-5
+    # a channel-slice view (ld > c) of a wider buffer as X: the buffer descriptor covers the view
+    wide = torch.zeros(xd.shape[:4] + (2 * cin,), dtype=torch.bfloat16, device=DEV)
+    wide[..., cin:] = xd
+    ops.conv3d_wgrad(wide[..., cin:], dyd, dw, None, k, s, ws)
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), w0.grad) < 5e-5
