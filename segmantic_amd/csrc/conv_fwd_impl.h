@@ -41,6 +41,7 @@ struct ConvParams {
   int ldbx;
   const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta; const float* balpha;
   float* bpart;
+  int xcd;   // ring2: 1 = XCD-aware blockIdx -> column map (grid.x % 8 == 0)
   int dbg;   // diagnostics only (SEGMI_RING2_DBG): 1 = no staging loads, 2 = no stores, 4 = no MFMA loop
 };
 

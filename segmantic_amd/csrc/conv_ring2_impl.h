@@ -50,9 +50,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
 
-  // (an XCD-aware workgroup -> column map -- XCD k = blockIdx % 8 taking the k-th eighth of the
-  // columns in raster order, so that x-neighbours share an L2 -- was measured neutral: 349 vs 349 us)
+  // XCD-aware workgroup -> column map: XCD k (= blockIdx % 8) takes the k-th eighth of the columns
+  // in raster order, so that x/y-neighbours share one L2 and their halos are fetched once.  L2 fetch
+  // of the 8 x 128^3 x 16 launch: 1.41x -> 1.02x of the input bytes.  Alone the launch is 1-2 % slower
+  // (361 -> 369 us: the re-fetches were MALL hits), inside the training step, where the weight-gradient
+  // stream competes for the fabric, it is 3 % faster (step 5.83 -> 5.78 ms).  SEGMI_RING2_XCD=0: off.
   int t = blockIdx.x;
+  if (p.xcd) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
   const int seg = t % p.tz; t /= p.tz;
   const int txi = t % p.tx; t /= p.tx;
   const int tyi = t % p.ty;
@@ -505,6 +509,7 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   p.tz = conv_ring_zsplit(dt, p.Cin, 3, 1, p.N, p.Do, p.Ho, p.Wo);
   static const int dbg = getenv("SEGMI_RING2_DBG") ? atoi(getenv("SEGMI_RING2_DBG")) : 0;
   p.dbg = dbg;
+  static const int xcd = getenv("SEGMI_RING2_XCD") ? atoi(getenv("SEGMI_RING2_XCD")) : 1;
   p.ty = cdiv(p.Ho, G::TH);
   p.tx = cdiv(p.Wo, G::TW);
   // 32-bit byte offsets inside one input / output plane
@@ -512,6 +517,7 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
                       (int64_t)p.Ho * p.Wo * (p.ldr > 0 ? p.ldr : 1) < (1ll << 31),
                   "conv3d: plane too large for the ring kernel's 32-bit offsets");
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
+  p.xcd = xcd != 0 && grid.x % 8 == 0;
   auto kern = conv_ring2_kernel<T, CK, NT, MODE>;
   static bool attr_done = false;
   if (!attr_done && G::LDS_BYTES + 6 * CK * 4 > 64 * 1024) {
