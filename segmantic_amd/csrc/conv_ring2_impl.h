@@ -123,8 +123,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   }
   // optional input transform: scale / shift of this thread's channel chunk (every 16-byte chunk a
   // thread stages has the same channel offset: 256 % CPR == 0).  Kept in LDS behind the ring and
-  // re-read where a chunk is committed -- no registers held across the MFMA loop (holding the 16
-  // values in registers for a whole commit phase makes every variant spill).
+  // re-read at the start of every commit phase -- no registers held across the MFMA loop.
   const bool in_tf = p.in_scale != nullptr;
   const bool in_act = in_tf && p.in_alpha != nullptr;
   float* tfs = reinterpret_cast<float*>(smem + G::LDS_BYTES);   // [2][CK]
@@ -138,25 +137,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
     return bn_prelu_bf16x8(v, sc, sh, in_alpha, in_act);
   };
-  auto transform_act = [&](frag_t v) {
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
-    return bn_prelu_bf16x8(v, sc, sh, in_alpha, true);
-  };
-  auto transform_act01 = [&](frag_t v) {
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
-    return bn_prelu01_bf16x8(v, sc, sh, in_alpha);
-  };
   const bool in_act01 = in_act && in_alpha >= 0.f && in_alpha <= 1.f;
-  auto transform_lin = [&](frag_t v) {
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = tfs[tf_ch + e]; sh[e] = tfs[CK + tf_ch + e]; }
-    return bn_prelu_bf16x8(v, sc, sh, 0.f, false);
-  };
   if (in_tf) __syncthreads();
   // prologue: planes z0-1 .. z0+4 -> ring slots 0 .. 5
 #pragma unroll
@@ -339,9 +320,23 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
         }
       };
       if (!in_tf) commit([](frag_t v) { return v; });
-      else if (in_act01) commit(transform_act01);
-      else if (in_act) commit(transform_act);
-      else commit(transform_lin);
+      else {
+        // scale / shift of the thread's channel chunk: read from LDS once per commit phase (the voxel
+        // fragments of the MFMA loop are dead here), not once per chunk -- 4 reads and one wait instead
+        // of 32 reads in 8 dependent groups.  The step-dependent zero keeps the reads inside the loop.
+        int tfo = tf_ch * 4;
+        asm volatile("" : "+v"(tfo));
+        float sc[8], sh[8];
+        const char* tb = reinterpret_cast<const char*>(tfs);
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          *reinterpret_cast<f32x4*>(&sc[e]) = *reinterpret_cast<const f32x4*>(tb + tfo + e * 4);
+          *reinterpret_cast<f32x4*>(&sh[e]) = *reinterpret_cast<const f32x4*>(tb + CK * 4 + tfo + e * 4);
+        }
+        if (in_act01) commit([&](frag_t v) { return bn_prelu01_bf16x8(v, sc, sh, in_alpha); });
+        else if (in_act) commit([&](frag_t v) { return bn_prelu_bf16x8(v, sc, sh, in_alpha, true); });
+        else commit([&](frag_t v) { return bn_prelu_bf16x8(v, sc, sh, 0.f, false); });
+      }
     }
     // every staging register is dead from here on; say so on ALL control-flow paths (touch_v)
 #pragma unroll
