@@ -399,11 +399,16 @@ def _starts(starts: Sequence[Sequence[int]], width: int):
     return arr, arr.ctypes.data_as(C.c_void_p)
 
 
+SW_MAX_WINDOWS = 16     # windows per segmi_sw_gather / segmi_sw_scatter_add call (kMaxWin in sliding.hip)
+
+
 def sw_gather(image, img_index, starts, windows) -> None:
-    a, b = act(image), act(windows)
-    arr, p = _starts(starts, 3)
-    check(lib.segmi_sw_gather(dtype_code(image), C.byref(a), img_index, p, arr.shape[0],
-                              dtype_code(windows), C.byref(b), _stream()), "sw_gather")
+    a = act(image)
+    for i in range(0, len(starts), SW_MAX_WINDOWS):      # larger groups: one launch per 16 windows
+        arr, p = _starts(starts[i:i + SW_MAX_WINDOWS], 3)
+        b = act(windows[i:i + arr.shape[0]])
+        check(lib.segmi_sw_gather(dtype_code(image), C.byref(a), img_index, p, arr.shape[0],
+                                  dtype_code(windows), C.byref(b), _stream()), "sw_gather")
 
 
 def sw_scatter_add(pred, starts, acc, cnt, importance=None) -> None:

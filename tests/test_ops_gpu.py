@@ -709,6 +709,19 @@ def test_sliding_window_ops_match_oracle():
         assert torch.equal(lab.cpu().long(), torch.argmax(ref, 1)[0])
 
 
+def test_sw_gather_more_than_16_windows_per_group():
+    """a window group larger than the kernel's 16 origins per launch is gathered in several launches"""
+    img = rnd((1, 1, 20, 27, 33), 95)
+    imd = img.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    roi = (8, 8, 8)
+    wins = [(z, y, x) for z in (0, 6, 12) for y in (0, 9, 19) for x in (0, 12, 25)]   # 27 windows
+    wd = torch.empty((len(wins),) + roi + (1,), device=DEV)
+    ops.sw_gather(imd, 0, wins, wd)
+    torch.cuda.synchronize()
+    for i, (z, y, x) in enumerate(wins):
+        assert torch.equal(wd[i, ..., 0].cpu(), img[0, 0, z:z + 8, y:y + 8, x:x + 8]), i
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("K", [4, 16, 3])
 def test_sliding_window_deferred_blend_matches_oracle(K, dtype):
