@@ -174,9 +174,11 @@ def test_conv3d_input_transform_equals_separate_bn_pass(c, cout, with_alpha, mod
     ops.conv3d_wgrad(u, dy, dw, None, 3, 1, ws, in_tf=tf)
     torch.cuda.synchronize()
     assert torch.equal(dw, dw_ref)
-    # layers off the ring kernel refuse the transform loudly
-    small = torch.empty((1, 4, 4, 4, 64), dtype=dtype, device=DEV)
+    # layers whose kernels cannot apply the transform say so (stride 2; 16-channel layers off the ring)
+    small = torch.empty((1, 4, 4, 4, 16), dtype=dtype, device=DEV)
     assert not ops.conv3d_in_affine_ok(small, small.clone(), 3, 1)
+    half = torch.empty((n,) + tuple((e + 1) // 2 for e in sp) + (cout,), dtype=dtype, device=DEV)
+    assert not ops.conv3d_in_affine_ok(u, half, 3, 2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
