@@ -316,12 +316,18 @@ def run_fit(args, rank, device, barrier, steps, warmup):
                             "label_dhw": lab[0, 0].contiguous()})
     rng = np.random.RandomState(0)
     order = [(2 * i % 4, (2 * i + 1) % 4) for i in range(warmup + steps)]
+    # the loop of trainer.run_epochs: step i is enqueued, then batch i + 1 is built on the prefetch stream
+    pre = trainer.BatchPrefetcher(net, cache)
+    pending = pre.prepare(order[0], rng)
     for i in range(warmup):
-        net.training_step(trainer.make_batch(net, cache, order[i], rng))
+        net.training_step(pre.take(pending))
+        pending = pre.prepare(order[i + 1], rng)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        net.training_step(trainer.make_batch(net, cache, order[warmup + i], rng))
+        net.training_step(pre.take(pending))
+        if i + 1 < steps:
+            pending = pre.prepare(order[warmup + i + 1], rng)
     barrier()
     dt = time.perf_counter() - t0
     return {"dt": dt, "units": args.batch * args.size ** 3 * steps, "volume": V}

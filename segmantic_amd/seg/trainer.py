@@ -150,6 +150,39 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
     return {"image": torch.cat(imgs).contiguous(), "label": torch.cat(labs).contiguous()}
 
 
+class BatchPrefetcher:
+    """Builds the next step's batch on a side HIP stream while the current step runs (the reference's
+    DataLoader workers do the same on host cores, ``monai_unet.py:278-286``).  The draws come from the
+    same ``rng`` in the same order as without it, so training is bit-identical either way;
+    ``SEGMI_PREFETCH=0`` builds every batch on the training stream instead."""
+
+    def __init__(self, net, cache: CachedVolumes):
+        self.net, self.cache = net, cache
+        self.enabled = os.environ.get("SEGMI_PREFETCH", "1") != "0"
+        self.stream = torch.cuda.Stream(device=cache.device) if self.enabled else None
+
+    def prepare(self, vol_ids, rng):
+        """enqueue the batch of ``vol_ids``; returns a handle for ``take``"""
+        if not self.enabled:
+            return (make_batch(self.net, self.cache, vol_ids, rng), None)
+        # no dependency on the training stream: the cache is static (synchronised when it was built)
+        with torch.cuda.stream(self.stream):
+            batch = make_batch(self.net, self.cache, vol_ids, rng)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return (batch, ev)
+
+    def take(self, handle) -> Dict:
+        """the batch, ordered before everything the training stream does next"""
+        batch, ev = handle
+        if ev is not None:
+            main = torch.cuda.current_stream(self.cache.device)
+            main.wait_event(ev)
+            for t in batch.values():
+                t.record_stream(main)       # allocated on the side stream, consumed on this one
+        return batch
+
+
 def epoch_shard(n: int, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
     """Volume indices of ``rank`` for ``epoch`` -- torch ``DistributedSampler`` (what Lightning
     injects for the reference's train loader, ``monai_unet.py:278-286,529-538``): ONE permutation
@@ -193,8 +226,11 @@ def sync_dataset(dataset):
 
 def run_epochs(net, n_train: int, step_fn: Callable, validate_fn: Callable, output_dir: Path,
                max_epochs: int, early_stop_patience: int, ckpt_name: Callable, batch_volumes: int,
-               seed: int, rank: int, world: int, device=None):
+               seed: int, rank: int, world: int, device=None, prepare_fn: Optional[Callable] = None):
     """The epoch loop of ``fit``: identical control flow on every rank.
+
+    ``prepare_fn(volume_ids, rng) -> handle`` (optional) builds a step's batch ahead of time; the
+    handle is then passed to ``step_fn(volume_ids, rng, handle)``.
 
     ``step_fn(volume_ids, rng) -> loss`` (scalar tensor or float) runs one ``training_step``;
     ``validate_fn() -> {"val_dice", "val_loss"}`` runs the validation epoch (its numbers are
@@ -215,9 +251,18 @@ def run_epochs(net, n_train: int, step_fn: Callable, validate_fn: Callable, outp
         t0 = time.time()
         order = epoch_shard(n_train, epoch, seed, rank, world)
         losses = []
-        for b in range(0, len(order), batch_volumes):
-            losses.append(step_fn(order[b:b + batch_volumes], rng))
-            steps_run += 1
+        groups = [order[b:b + batch_volumes] for b in range(0, len(order), batch_volumes)]
+        if prepare_fn is None:
+            for ids in groups:
+                losses.append(step_fn(ids, rng))
+                steps_run += 1
+        else:
+            # step i is enqueued first, then the batch of step i + 1 is built beside it
+            pending = prepare_fn(groups[0], rng) if groups else None
+            for i, ids in enumerate(groups):
+                losses.append(step_fn(ids, rng, pending))
+                pending = prepare_fn(groups[i + 1], rng) if i + 1 < len(groups) else None
+                steps_run += 1
         if losses and torch.is_tensor(losses[0]):
             train_loss = float(torch.stack([l.reshape(()) for l in losses]).mean().item())
         else:
@@ -278,8 +323,10 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
     train_cache = CachedVolumes(net.dataset.training_files(), device, net.num_classes, spacing)
     val_cache = CachedVolumes(net.dataset.validation_files(), device, net.num_classes, spacing)
 
-    def step_fn(vol_ids, rng):                    # set_determinism(seed=0), reference :229
-        return net.training_step(make_batch(net, train_cache, vol_ids, rng))["loss"]
+    prefetch = BatchPrefetcher(net, train_cache)
+
+    def step_fn(vol_ids, rng, handle):            # set_determinism(seed=0), reference :229
+        return net.training_step(prefetch.take(handle))["loss"]
 
     def validate_fn():
         if world > 1:
@@ -289,5 +336,6 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
         return net.on_validation_epoch_end(sync=lambda *v: sync_from_rank0(v, device))
 
     run_epochs(net, len(train_cache), step_fn, validate_fn, output_dir, max_epochs,
-               early_stop_patience, ckpt_name, batch_volumes, seed, rank, world, device)
+               early_stop_patience, ckpt_name, batch_volumes, seed, rank, world, device,
+               prepare_fn=prefetch.prepare)
     return net

@@ -282,6 +282,32 @@ def test_training_with_spatial_and_intensity_augmentation(tmp_path):
             assert bool((lab == lab.round()).all()) and 0 <= float(lab.min()) and float(lab.max()) <= 2
 
 
+def test_fit_with_batch_prefetch_is_bit_identical_to_the_serial_sampler(tmp_path, monkeypatch):
+    """the next step's batch is built on a side stream while the current step runs (BatchPrefetcher):
+    same draws in the same order, so the trained weights equal those of the serial loop bit for bit"""
+    import warnings
+
+    from segmantic_amd.seg.monai_unet import Net, train
+    datalist = _write_dataset(tmp_path / "data")
+    weights = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SEGMI_PREFETCH", flag)
+        torch.manual_seed(1234)
+        np.random.seed(1234)
+        out = tmp_path / f"results{flag}"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            train(datalist=datalist, output_dir=out, spatial_size=[16, 16, 16], channels=(16, 32, 64),
+                  strides=(2, 2), max_epochs=2, mixed_precision=True, num_samples=2, gpu_ids=[0],
+                  augment_intensity=True)
+        ck = sorted(out.glob("epoch=*.ckpt"))[-1]
+        sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
+        weights.append(sd)
+    assert weights[0].keys() == weights[1].keys()
+    for k in weights[0]:
+        assert torch.equal(weights[0][k], weights[1][k]), k
+
+
 def test_cross_validate_and_ensemble_predict(tmp_path):
     """`cross-validate` (k-fold data lists, one training process per fold) and `ensemble-predict`
     (mean / vote / select_best) of the reference CLI on the GPU path."""
