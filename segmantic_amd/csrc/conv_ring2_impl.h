@@ -214,6 +214,18 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   for (int ro = 0; ro < 2; ++ro) b_off[ro] = (unsigned)(((oy0 + 2 * wave + ro) * p.Wo + ox0 + r) * p.ldbx + co);
   const int64_t bplane = (int64_t)p.Ho * p.Wo * p.ldbx;
 
+  // Plane addresses are a per-workgroup 64-bit base (loop-invariant) + a 32-bit product (the launcher
+  // checks that one sample's tensors stay below 2^31 elements): the 64-bit products
+  // ((n * Do + oz) * plane) and the ring slot's "% R" were dependent scalar chains of 8-14
+  // instructions per plane in front of every load / store group.
+  const char* const in_base = img + (int64_t)(z0 + 5) * plane_stride;         // plane z0 + 5
+  T* const out_base = outp + ((int64_t)n * p.Do + z0) * oplane;               // plane z0
+  const T* const res_base = resp ? resp + ((int64_t)n * p.Do + z0) * rplane : nullptr;
+  const T* const bx_base = BSUM ? bxp + ((int64_t)n * p.Do + z0) * bplane : nullptr;
+  const unsigned plane_b32 = (unsigned)plane_stride, oplane32 = (unsigned)oplane,
+                 rplane32 = (unsigned)rplane, bplane32 = (unsigned)bplane;
+  int slot0 = 0;                                                               // zb % R
+  auto ring_slot = [&](int c) { const int v = slot0 + c; return v >= G::R ? v - G::R : v; };
   for (int step = 0; step < nsteps_z; ++step) {
     const int zb = step * G::TD;
     const bool more = step + 1 < nsteps_z;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
     for (int pl = 0; pl < G::TD; ++pl) {
       const int z = z0 + zb + 5 + pl;
-      const char* pp = img + (int64_t)z * plane_stride;
+      const char* pp = in_base + (unsigned)(zb + pl) * plane_b32;
       const bool zok = more && z < p.Di && !RING2_DBG(p, 1);
 #pragma unroll
       for (int q = 0; q < NLP; ++q) {
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
       for (int zi = 0; zi < 4; ++zi) {
         const int oz = z0 + zb + zi;
-        const T* rp = resp + ((int64_t)n * p.Do + oz) * rplane;
+        const T* rp = res_base + (unsigned)(zb + zi) * rplane32;
 #pragma unroll
         for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     typename Raw4<T>::type bxv[BSUM ? 4 : 1][2][NT];
     auto fetch_bx = [&](int zi) {
       const int oz = z0 + zb + zi;
-      const T* bp = bxp + ((int64_t)n * p.Do + oz) * bplane;
+      const T* bp = bx_base + (unsigned)(zb + zi) * bplane32;
 #pragma unroll
       for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     f32x4 acc[4][2][NT];
     int pofs[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c) % G::R) * G::PLANE_B + wrow;
+    for (int c = 0; c < 6; ++c) pofs[c] = ring_slot(c) * G::PLANE_B + wrow;
     // software pipeline over the (plane, k-step) iterations, fragments PD iterations ahead (an
     // iteration is 2 - 6 MFMAs = 32 - 96 clk against >= 128 clk of loaded LDS latency; the depth is
     // what the variant's register budget allows)
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       auto commit = [&](auto tf) {
 #pragma unroll
         for (int pl = 0; pl < G::TD; ++pl) {
-          const int slot = (zb + 6 + pl) % G::R;
+          const int slot = ring_slot(6 + pl);
           const bool zin = z0 + zb + 5 + pl < p.Di;
 #pragma unroll
           for (int q = 0; q < NLP; ++q) {
@@ -386,13 +398,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
     for (int zi = 0; zi < 4; ++zi) {
       const int oz = z0 + zb + zi;
-      T* op = outp + ((int64_t)n * p.Do + oz) * oplane;   // wave-uniform plane pointer
+      T* op = out_base + (unsigned)(zb + zi) * oplane32;   // wave-uniform plane pointer
       const int rz = PRE_RES ? zi : 0;
       if constexpr (!PRE_RES) {
         if (res_in) {
           lds_res(zi, resv[0]);
         } else if (resp) {
-          const T* rp = resp + ((int64_t)n * p.Do + oz) * rplane;
+          const T* rp = res_base + (unsigned)(zb + zi) * rplane32;
 #pragma unroll
           for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
           }
         }
     }
+    slot0 = slot0 + G::TD >= G::R ? slot0 + G::TD - G::R : slot0 + G::TD;
     __syncthreads();
   }
 
@@ -511,6 +524,13 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   SEGMI_CHECK_ARG((int64_t)p.Hi * p.Wi * p.ldi * 2 < (1ll << 31) && (int64_t)p.Ho * p.Wo * p.ldo < (1ll << 31) &&
                       (int64_t)p.Ho * p.Wo * (p.ldr > 0 ? p.ldr : 1) < (1ll << 31),
                   "conv3d: plane too large for the ring kernel's 32-bit offsets");
+  // plane index x plane size as a 32-bit product: one sample of every operand below 2^31 (bytes for
+  // the input, elements for the others)
+  SEGMI_CHECK_ARG((int64_t)(p.Di + 8) * p.Hi * p.Wi * p.ldi * 2 < (1ll << 31) &&
+                      (int64_t)(p.Do + 4) * p.Ho * p.Wo * p.ldo < (1ll << 31) &&
+                      (int64_t)(p.Do + 4) * p.Ho * p.Wo * (p.ldr > 0 ? p.ldr : 1) < (1ll << 31) &&
+                      (int64_t)(p.Do + 4) * p.Ho * p.Wo * (p.ldbx > 0 ? p.ldbx : 1) < (1ll << 31),
+                  "conv3d: sample too large for the ring kernel's 32-bit plane offsets");
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
   p.xcd = xcd != 0 && grid.x % 8 == 0;
   auto kern = conv_ring2_kernel<T, CK, NT, MODE>;
