@@ -14,3 +14,7 @@ lib=$L/libsegmi.so; [ $v = old ] && lib=$L/libsegmi_old.so
 SEGMI_LIB=$lib timeout -k 10 200 python3 bench.py --workload infer --no-cpu-baseline --steps 4 --warmup 1 > gpurun_out/r2/ab.log 2>&1 || { tail -5 gpurun_out/r2/ab.log; exit 1; }
 python3 -c "import sys,json; d=json.loads(open('gpurun_out/r2/ab.log').read().strip().splitlines()[-1]); print('$v infer', d['value'])"
 done
+for v in new old new old; do
+lib=$L/libsegmi.so; [ $v = old ] && lib=$L/libsegmi_old.so
+SEGMI_LIB=$lib timeout -k 10 120 python3 scripts/ring2_diag.py 8 | sed "s/^/$v /" || exit 1
+done

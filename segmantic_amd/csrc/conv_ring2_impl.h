@@ -22,7 +22,8 @@
 #include "conv_ring_impl.h"
 
 // Time-split diagnostic (build with -DSEGMI_RING2_DIAG, run with SEGMI_RING2_DBG=bits: 1 = no staging
-// loads, 2 = no stores, 4 = no MFMA loop; scripts/ring2_diag.py).  Compiled out of the product build:
+// loads, 2 = no stores, 4 = no MFMA loop, 8 = no commit, 16 = no epilogue, 32 = no end-of-step barrier
+// (only meaningful together with 4 + 8); scripts/ring2_diag.py).  Compiled out of the product build:
 // the extra live flag costs the 32 -> 64 variant its last free registers.
 #ifdef SEGMI_RING2_DIAG
 #define RING2_DBG(p, bit) (((p).dbg & (bit)) != 0)
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- write the prefetched planes into the free ring slots (zb+6 .. zb+9 mod R)
-    if (more) {
+    if (more && !RING2_DBG(p, 8)) {
       // three copies of the commit loop behind wave-uniform branches (none / affine / affine +
       // PReLU) instead of per-element selects on the two runtime flags
       auto commit = [&](auto tf) {
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       }
     }
     // ---- epilogue of this step
+    if (!RING2_DBG(p, 16))
 #pragma unroll
     for (int zi = 0; zi < 4; ++zi) {
       const int oz = z0 + zb + zi;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
         }
     }
     slot0 = slot0 + G::TD >= G::R ? slot0 + G::TD - G::R : slot0 + G::TD;
-    __syncthreads();
+    if (!RING2_DBG(p, 32)) __syncthreads();
   }
 
   if constexpr (BSUM) {
