@@ -321,11 +321,13 @@ def run_fit(args, rank, device, barrier, steps, warmup):
     pending = pre.prepare(order[0], rng)
     for i in range(warmup):
         net.training_step(pre.take(pending))
+        pre.release(pending)
         pending = pre.prepare(order[i + 1], rng)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         net.training_step(pre.take(pending))
+        pre.release(pending)
         if i + 1 < steps:
             pending = pre.prepare(order[warmup + i + 1], rng)
     barrier()

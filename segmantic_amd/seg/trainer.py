@@ -120,19 +120,40 @@ def crop_centers(rng: np.random.RandomState, item: Dict, roi, num_samples: int, 
     return starts
 
 
-def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
-    """2 volumes x num_samples crops -> {'image': [B,C,*roi] f32, 'label': [B,1,*roi] f32}."""
+def batch_buffers(net, cache: CachedVolumes, n_volumes: int) -> Dict:
+    """destination of ``make_batch(..., out=)``: NDHWC image and label buffers of one batch"""
+    roi = list(net.spatial_size)
+    B = n_volumes * net.num_samples
+    C = cache.items[0]["image"].shape[0]
+    dev = cache.device
+    return {"image": torch.empty((B, roi[0], roi[1], roi[2], C), dtype=torch.float32, device=dev),
+            "label": torch.empty((B, roi[0], roi[1], roi[2]), dtype=torch.float32, device=dev)}
+
+
+def make_batch(net, cache: CachedVolumes, vol_ids, rng, out: Optional[Dict] = None) -> Dict:
+    """2 volumes x num_samples crops -> {'image': [B,C,*roi] f32, 'label': [B,1,*roi] f32}.
+
+    ``out`` (``batch_buffers``): the crops are written straight into these buffers -- no allocation
+    and no concatenation per step; the returned tensors are views of them (the image as the
+    NCDHW-shaped view of the NDHWC buffer the crop kernels fill)."""
     roi = list(net.spatial_size)
     dev = net.device
     imgs, labs = [], []
+    row = 0
     for vid in vol_ids:
         it = cache.items[vid]
         spatial = draw_spatial(rng, it["label"].shape[1:]) if net.augment_spatial else None
         starts = crop_centers(rng, it, roi, net.num_samples, net.num_classes, spatial, cache)
         C = it["image"].shape[0]
         src = it["image_ndhwc"]                                              # NDHWC, n = 1
-        out_i = torch.empty((len(starts), roi[0], roi[1], roi[2], C), dtype=torch.float32, device=dev)
-        out_l = torch.empty((len(starts), roi[0], roi[1], roi[2]), dtype=torch.float32, device=dev)
+        if out is not None and out["image"].shape[0] >= row + len(starts) and out["image"].shape[4] == C:
+            out_i = out["image"][row:row + len(starts)]
+            out_l = out["label"][row:row + len(starts)]
+        else:
+            out = None
+            out_i = torch.empty((len(starts), roi[0], roi[1], roi[2], C), dtype=torch.float32, device=dev)
+            out_l = torch.empty((len(starts), roi[0], roi[1], roi[2]), dtype=torch.float32, device=dev)
+        row += len(starts)
         fp = float(getattr(net, "flip_prob", 0.2))
         flips = [(int(rng.rand() < fp)) | (int(rng.rand() < fp) << 1) | (int(rng.rand() < fp) << 2)
                  for _ in starts]
@@ -147,40 +168,70 @@ def make_batch(net, cache: CachedVolumes, vol_ids, rng) -> Dict:
             ops.kspace_augment(out_i, gibbs, spike)
         imgs.append(out_i.permute(0, 4, 1, 2, 3))
         labs.append(out_l.unsqueeze(1))
+    if out is not None:
+        img = out["image"][:row].permute(0, 4, 1, 2, 3)
+        return {"image": img if img.is_contiguous() else img.contiguous(), "label": out["label"][:row].unsqueeze(1)}
     return {"image": torch.cat(imgs).contiguous(), "label": torch.cat(labs).contiguous()}
 
 
 class BatchPrefetcher:
     """Builds the next step's batch on a side HIP stream while the current step runs (the reference's
     DataLoader workers do the same on host cores, ``monai_unet.py:278-286``).  The draws come from the
-    same ``rng`` in the same order as without it, so training is bit-identical either way;
-    ``SEGMI_PREFETCH=0`` builds every batch on the training stream instead."""
+    same ``rng`` in the same order as without it, so training is bit-identical either way.
+    OFF by default (``SEGMI_PREFETCH=1`` enables it): the process already uses four streams (training,
+    weight gradients, residual branch, sampler) and ROCm maps streams onto 4 hardware queues
+    (``GPU_MAX_HW_QUEUES``); a fifth stream that lands on the training stream's queue serialises
+    behind it and costs more than the overlap gains (5.80 vs 5.87 ms per step when it gets its own queue,
+    6.4-6.5 vs 5.9 ms when it does not -- measured after other workloads had created streams).
+
+    Two persistent buffer sets alternate (no allocation per step: tensors handed from one stream's
+    allocator pool to another would keep the pool growing for several steps): set k is refilled only
+    after the step that read it has been enqueued completely (``release``)."""
 
     def __init__(self, net, cache: CachedVolumes):
         self.net, self.cache = net, cache
-        self.enabled = os.environ.get("SEGMI_PREFETCH", "1") != "0"
+        self.enabled = os.environ.get("SEGMI_PREFETCH", "0") == "1"
         self.stream = torch.cuda.Stream(device=cache.device) if self.enabled else None
+        self._sets: List[Optional[Dict]] = [None, None]
+        self._released: List[Optional[torch.cuda.Event]] = [None, None]
+        self._turn = 0
 
     def prepare(self, vol_ids, rng):
-        """enqueue the batch of ``vol_ids``; returns a handle for ``take``"""
+        """enqueue the batch of ``vol_ids``; returns a handle for ``take`` / ``release``"""
+        k = self._turn
+        self._turn ^= 1
+        if self._sets[k] is None or self._sets[k]["image"].shape[0] < len(vol_ids) * self.net.num_samples:
+            self._sets[k] = batch_buffers(self.net, self.cache, len(vol_ids))
+            self._released[k] = None
         if not self.enabled:
-            return (make_batch(self.net, self.cache, vol_ids, rng), None)
-        # no dependency on the training stream: the cache is static (synchronised when it was built)
+            return (make_batch(self.net, self.cache, vol_ids, rng, out=self._sets[k]), None, k)
+        # no dependency on the training stream except the buffer set's previous reader: the cache is
+        # static (synchronised when it was built)
+        if self._released[k] is not None:
+            self.stream.wait_event(self._released[k])
         with torch.cuda.stream(self.stream):
-            batch = make_batch(self.net, self.cache, vol_ids, rng)
+            batch = make_batch(self.net, self.cache, vol_ids, rng, out=self._sets[k])
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        return (batch, ev)
+        return (batch, ev, k)
 
     def take(self, handle) -> Dict:
         """the batch, ordered before everything the training stream does next"""
-        batch, ev = handle
+        batch, ev, _k = handle
         if ev is not None:
             main = torch.cuda.current_stream(self.cache.device)
             main.wait_event(ev)
             for t in batch.values():
-                t.record_stream(main)       # allocated on the side stream, consumed on this one
+                t.record_stream(main)       # (only matters for tensors make_batch had to allocate)
         return batch
+
+    def release(self, handle) -> None:
+        """call once the step that reads the batch has been enqueued: its buffer set may be refilled"""
+        _batch, ev, k = handle
+        if ev is not None:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.cache.device))
+            self._released[k] = done
 
 
 def epoch_shard(n: int, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
@@ -326,7 +377,9 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
     prefetch = BatchPrefetcher(net, train_cache)
 
     def step_fn(vol_ids, rng, handle):            # set_determinism(seed=0), reference :229
-        return net.training_step(prefetch.take(handle))["loss"]
+        loss = net.training_step(prefetch.take(handle))["loss"]
+        prefetch.release(handle)
+        return loss
 
     def validate_fn():
         if world > 1:
