@@ -25,6 +25,11 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     """Initialise torch.distributed from the torchrun environment (idempotent)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
+        # A rank drives more streams than ROCm's default 4 hardware queues (training, weight gradients,
+        # residual branch, sampler, gradient buckets + RCCL's own): streams that share a queue run in
+        # order, which would put the bucket all-reduces behind the backward they are meant to overlap.
+        # Read by the HIP runtime when it initialises, i.e. before the first device call below.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         if backend is None:
             # SEGMI_DIST_BACKEND=gloo: rehearse the multi-process path where RCCL cannot run (several
             # ranks sharing one GPU, CPU-only boxes); the product default on GPUs is nccl = RCCL
