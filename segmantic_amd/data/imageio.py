@@ -101,13 +101,19 @@ def _read_nrrd(path: Path) -> Tuple[np.ndarray, np.ndarray]:
     raw = path.read_bytes()
     if not raw.startswith(b"NRRD"):
         raise ValueError(f"{path}: not an NRRD file")
-    end = raw.index(b"\n\n")
+    # the header ends at the first blank line (LF or CRLF line ends)
+    ends = [(raw.find(sep), len(sep)) for sep in (b"\n\n", b"\r\n\r\n") if raw.find(sep) >= 0]
+    if not ends:
+        raise ValueError(f"{path}: NRRD header has no terminating blank line")
+    end, seplen = min(ends)
     hdr = {}
-    for line in raw[:end].decode("latin1").split("\n")[1:]:
+    for line in raw[:end].decode("latin1").splitlines()[1:]:
         if line.startswith("#") or ":" not in line:
             continue
         k, v = line.split(":", 1)
         hdr[k.strip().lower()] = v.lstrip("=").strip()
+    if "data file" in hdr or "datafile" in hdr:
+        raise ValueError(f"{path}: detached NRRD headers (data file: ...) are not supported")
     if int(hdr["dimension"]) != 3:
         raise ValueError(f"{path}: only 3-D NRRD volumes are supported")
     size = [int(v) for v in hdr["sizes"].split()]
@@ -126,7 +132,7 @@ def _read_nrrd(path: Path) -> Tuple[np.ndarray, np.ndarray]:
         lps = False
     else:
         raise ValueError(f"{path}: NRRD space '{space}' is not supported (LPS / RAS)")
-    data = raw[end + 2:]
+    data = raw[end + seplen:]
     enc = hdr.get("encoding", "raw").lower()
     if enc in ("gzip", "gz"):
         data = gzip.decompress(data)

@@ -395,6 +395,13 @@ def test_image_io_nifti_metaimage_nrrd_round_trip_and_lps_to_ras(tmp_path):
     (tmp_path / "r.nrrd").write_bytes(nh.encode() + data.tobytes())
     arr3, A4 = read_image(tmp_path / "r.nrrd")
     assert np.array_equal(arr3, data) and np.allclose(A4, np.array([[0.5, 0, 0, 1], [0, 0.6, 0, 2], [0, 0, 0.7, 3], [0, 0, 0, 1.0]]))
+    # the same header with CRLF line ends; a detached header is refused by name
+    (tmp_path / "c.nrrd").write_bytes(nh.replace("\n", "\r\n").encode() + data.tobytes())
+    arr4, A5 = read_image(tmp_path / "c.nrrd")
+    assert np.array_equal(arr4, data) and np.allclose(A5, A4)
     import pytest
+    (tmp_path / "d.nrrd").write_bytes(nh.replace("encoding: raw", "encoding: raw\ndata file: d.raw").encode())
+    with pytest.raises(ValueError, match="detached"):
+        read_image(tmp_path / "d.nrrd")
     with pytest.raises(ValueError, match="unsupported image format"):
         read_image(tmp_path / "x.png")
