@@ -83,3 +83,58 @@ def test_two_rank_step_equals_manual_gradient_average(tmp_path):
     ref = master._engine.flat.detach().cpu()
     # identical arithmetic (sum of two f32 gradients, scale 1/2 inside Adam) -> bit exact
     assert torch.equal(f0, ref), float((f0 - ref).abs().max())
+
+
+def _fit_worker(rank, world, port, datalist, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", SEGMI_DIST_BACKEND="gloo")
+    import warnings
+
+    from segmantic_amd.seg.monai_unet import train
+    torch.manual_seed(7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = train(datalist=datalist, output_dir=out_dir, spatial_size=[16, 16, 16], channels=CH, strides=ST,
+                    max_epochs=2, mixed_precision=True, num_samples=2, gpu_ids=[0, 0])
+    torch.cuda.synchronize()
+    torch.save({"flat": net._engine.flat.detach().cpu(), "best": net.best_val_dice},
+               os.path.join(str(out_dir), f"final_rank{rank}.pt"))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_two_rank_fit_runs_the_reference_train_entry_point_end_to_end(tmp_path):
+    """`train()` under a 2-rank launch (both ranks on the one GPU, gloo): rank 0's split is shared, every
+    rank runs the same number of steps with 5 training volumes (DistributedSampler padding), validation
+    numbers come from rank 0, only rank 0 writes checkpoints / Dataset.json / the CSV log, and the ranks
+    end with identical weights."""
+    import json
+
+    import numpy as np
+    from oracle.unet_ref import synthetic_batch
+    from segmantic_amd.data.nifti import write_nifti
+    root = tmp_path / "data"
+    (root / "image").mkdir(parents=True)
+    (root / "label").mkdir()
+    A = np.diag([1.0, 1.0, 1.0, 1.0])
+    n = 7
+    for i in range(n):
+        img, lab = synthetic_batch(1, 24, 3, seed=40 + i)
+        write_nifti(root / "image" / f"c{i}.nii.gz", (img[0, 0].numpy() * 100 + 300).astype(np.float32).transpose(2, 1, 0), A)
+        write_nifti(root / "label" / f"c{i}.nii.gz", lab[0, 0].numpy().astype(np.uint8).transpose(2, 1, 0), A)
+    dl = {"labels": {"1": "a", "2": "b"},
+          "training": [{"image": f"image/c{i}.nii.gz", "label": f"label/c{i}.nii.gz"} for i in range(5)],
+          "validation": [{"image": f"image/c{i}.nii.gz", "label": f"label/c{i}.nii.gz"} for i in (5, 6)],
+          "test": []}
+    (root / "dataset.json").write_text(json.dumps(dl))
+    out = tmp_path / "results"
+    port = _free_port()
+    mp.spawn(_fit_worker, args=(2, port, root / "dataset.json", out), nprocs=2, join=True)
+    ckpts = sorted(out.glob("epoch=*-val_loss=*-val_dice=*.ckpt"))
+    assert 1 <= len(ckpts) <= 2                      # written once (rank 0), at most one per epoch
+    rows = (out / "logs" / "metrics.csv").read_text().strip().splitlines()
+    assert len(rows) == 3 and all(np.isfinite(float(r.split(",")[1])) for r in rows[1:])
+    assert (out / "Dataset.json").exists()
+    r0, r1 = torch.load(out / "final_rank0.pt"), torch.load(out / "final_rank1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])       # replicas never diverge
+    assert r0["best"] == r1["best"]                  # the validation number is rank 0's on every rank
