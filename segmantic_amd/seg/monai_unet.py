@@ -512,6 +512,7 @@ def predict(
 
     all_mean_dice = []
     class_dice_sum, class_dice_cnt = None, None
+    per_volume = []            # (index in test_images, per-class Dice row): what a multi-rank run gathers
     with torch.no_grad():
         for i, img_path in enumerate(test_images):
             if i % world != rank:
@@ -526,6 +527,7 @@ def predict(
                 d = dice_metric(pred_lab, item["label"][None].long())
                 conf_matrix(pred_lab, item["label"][None].long())
                 dn = d.cpu().numpy()
+                per_volume.append((i, d.cpu()))
                 print("Mean Dice: ", np.nanmean(dn))
                 print("Class Dice:")
                 print_table(tissue_names[1:], np.squeeze(dn))
@@ -538,11 +540,17 @@ def predict(
             import torch.distributed as dist
             parts = [None] * world
             conf_local = torch.cat(conf_matrix._items).cpu() if conf_matrix._items else None
-            dist.all_gather_object(parts, (all_mean_dice, class_dice_sum, class_dice_cnt, conf_local))
+            dist.all_gather_object(parts, (per_volume, class_dice_sum, class_dice_cnt, conf_local))
             if rank != 0:
                 return
             conf_matrix._items = [p[3] for p in parts if p[3] is not None]
-            all_mean_dice = [v for p in parts for v in p[0]]
+            # the score file holds the RUNNING aggregate after every volume (reference :664): rebuild it
+            # from all ranks' per-volume rows in the order of `test_images`, as one process would have
+            running = DiceMetric(num_classes, include_background=False)
+            all_mean_dice = []
+            for _i, row in sorted((t for p in parts for t in p[0]), key=lambda t: t[0]):
+                running._items.append(row)
+                all_mean_dice.append(float(running.aggregate().item()))
             sums = [p[1] for p in parts if p[1] is not None]
             class_dice_sum = sum(sums) if sums else None
             class_dice_cnt = sum(p[2] for p in parts if p[2] is not None) if sums else None

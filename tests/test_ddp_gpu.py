@@ -138,3 +138,52 @@ def test_two_rank_fit_runs_the_reference_train_entry_point_end_to_end(tmp_path):
     r0, r1 = torch.load(out / "final_rank0.pt"), torch.load(out / "final_rank1.pt")
     assert torch.equal(r0["flat"], r1["flat"])       # replicas never diverge
     assert r0["best"] == r1["best"]                  # the validation number is rank 0's on every rank
+
+
+def _predict_worker(rank, world, port, ckpt, images, labels, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", SEGMI_DIST_BACKEND="gloo")
+    from segmantic_amd.seg.monai_unet import predict
+    predict(model_file=ckpt, test_images=images, test_labels=labels, output_dir=out_dir,
+            tissue_dict={"bg": 0, "a": 1, "b": 2}, channels=CH, strides=ST, gpu_ids=[0, 0])
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_two_rank_predict_equals_the_single_process_run(tmp_path):
+    """`predict()` under a 2-rank launch: volumes dealt round-robin, label files identical to the
+    single-process run, the score file in `test_images` order."""
+    import warnings
+
+    import numpy as np
+    from oracle.unet_ref import synthetic_batch
+    from segmantic_amd.data.nifti import read_nifti, write_nifti
+    from segmantic_amd.seg.monai_unet import Net, predict
+    root = tmp_path / "data"
+    root.mkdir()
+    A = np.diag([1.0, 1.0, 1.0, 1.0])
+    images, labels = [], []
+    for i in range(3):
+        img, lab = synthetic_batch(1, 24, 3, seed=60 + i)
+        write_nifti(root / f"i{i}.nii.gz", (img[0, 0].numpy() * 100 + 300).astype(np.float32).transpose(2, 1, 0), A)
+        write_nifti(root / f"l{i}.nii.gz", lab[0, 0].numpy().astype(np.uint8).transpose(2, 1, 0), A)
+        images.append(root / f"i{i}.nii.gz")
+        labels.append(root / f"l{i}.nii.gz")
+    torch.manual_seed(3)
+    net = Net(num_classes=3, channels=CH, strides=ST, spatial_size=[16, 16, 16]).to("cuda:0")
+    ckpt = tmp_path / "m.ckpt"
+    net.save_checkpoint(ckpt, epoch=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict(model_file=ckpt, test_images=images, test_labels=labels, output_dir=tmp_path / "one",
+                tissue_dict={"bg": 0, "a": 1, "b": 2}, channels=CH, strides=ST, gpu_ids=[0])
+    port = _free_port()
+    mp.spawn(_predict_worker, args=(2, port, ckpt, images, labels, tmp_path / "two"), nprocs=2, join=True)
+    for i in range(3):
+        a, _ = read_nifti(tmp_path / "one" / f"i{i}.nii.gz")
+        b, _ = read_nifti(tmp_path / "two" / f"i{i}.nii.gz")
+        assert np.array_equal(a, b), i
+    s1 = np.loadtxt(tmp_path / "one" / "mean_dice_m_generalized_score.txt", delimiter=",")
+    s2 = np.loadtxt(tmp_path / "two" / "mean_dice_m_generalized_score.txt", delimiter=",")
+    # (the running mean is taken on the device in one process and on gathered host rows on rank 0: 1 ulp)
+    assert s1.shape == s2.shape == (3,) and np.allclose(s1, s2, rtol=1e-6, atol=0)
