@@ -62,6 +62,9 @@ class GradSync:
         self._hi = self.n          # everything in [_hi, n) has been launched
         self._works: List = []
         self._side = torch.cuda.Stream() if flat_grad.is_cuda else None
+        # SEGMI_GRADSYNC_FORCE=1: issue the collectives even with one rank (a sum over one rank is the
+        # identity) -- lets a one-GPU box run the whole RCCL path: side stream, events, Work.wait()
+        self._force = os.environ.get("SEGMI_GRADSYNC_FORCE") == "1" and dist.is_initialized()
 
     @property
     def grad_scale(self) -> float:
@@ -91,14 +94,14 @@ class GradSync:
     def ready(self, lo: int, after=()):
         """gradients at offsets >= lo are final once the current stream's present point and the
         events in ``after`` (work of other streams, e.g. the weight-gradient stream) are reached"""
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         while self._hi - lo >= self.bucket_elems:
             self._launch(self._hi - self.bucket_elems, self._hi, after)
             self._hi -= self.bucket_elems
 
     def finish(self, after=()):
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         self._launch(0, self._hi, after)
         self._hi = 0

@@ -187,3 +187,29 @@ def test_two_rank_predict_equals_the_single_process_run(tmp_path):
     s2 = np.loadtxt(tmp_path / "two" / "mean_dice_m_generalized_score.txt", delimiter=",")
     # (the running mean is taken on the device in one process and on gathered host rows on rank 0: 1 ulp)
     assert s1.shape == s2.shape == (3,) and np.allclose(s1, s2, rtol=1e-6, atol=0)
+
+
+def _rccl_worker(rank, world, port, out_dir, force):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      SEGMI_GRADSYNC_FORCE="1" if force else "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)          # nccl = RCCL on ROCm
+    net = _make_net()
+    gs = net.enable_grad_sync(bucket_bytes=64 << 10)
+    assert gs.world == 1 and gs._force == bool(force)
+    for step in range(3):
+        net.training_step(_batch(0))
+    torch.cuda.synchronize()
+    torch.save(net._engine.flat.detach().cpu(), os.path.join(out_dir, f"rccl_{int(force)}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_through_rccl_with_one_rank(tmp_path):
+    """The box has one GPU, so RCCL cannot run a real exchange -- but it can run the whole path: process
+    group `nccl`, every gradient bucket all-reduced (over one rank: the identity) on the side stream
+    behind the engine's events, `Work.wait()` on the training stream.  Three steps must leave exactly
+    the weights of the same steps without the collectives."""
+    port = _free_port()
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path), True), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), False), nprocs=1, join=True)
+    assert torch.equal(torch.load(tmp_path / "rccl_1.pt"), torch.load(tmp_path / "rccl_0.pt"))
