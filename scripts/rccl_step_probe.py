@@ -11,11 +11,20 @@ import bench
 sys.argv = ["bench.py"]
 args = bench.parse()
 net = bench.make_net(args.classes, args.size, "bf16", torch.device("cuda:0")).train()
-net.enable_grad_sync()
+gs = net.enable_grad_sync()
+sizes = []
+_launch = gs._launch
+def counting(lo, hi, after=()):
+    if hi > lo:
+        sizes.append((hi - lo) * 4 // 1024)
+    return _launch(lo, hi, after)
+gs._launch = counting
 img, lab = bench.synthetic(args.batch, args.size, args.classes, 0, torch.device("cuda:0"))
 batch = {"image": img, "label": lab}
 for _ in range(5):
+    sizes.clear()
     net.training_step(batch)
+print("collectives per step (KiB):", sizes, flush=True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30):
     net.training_step(batch)

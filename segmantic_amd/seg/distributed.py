@@ -58,6 +58,7 @@ class GradSync:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.tail_min_elems = min(self.bucket_elems, 16384)   # no collectives below 64 KB before finish()
         self.n = flat_grad.numel()
         self._hi = self.n          # everything in [_hi, n) has been launched
         self._works: List = []
@@ -99,6 +100,13 @@ class GradSync:
         while self._hi - lo >= self.bucket_elems:
             self._launch(self._hi - self.bucket_elems, self._hi, after)
             self._hi -= self.bucket_elems
+        # Tail rule: once less than one bucket of the arena is still being computed, do not hold final
+        # gradients back for a full bucket -- send what is final now (the deep down-path layers, final
+        # ~0.3 ms before the first layer's), so that finish(), whose collective is exposed after the
+        # backward, only carries the first layers (a few 10 KB instead of up to a whole bucket).
+        if lo < self.bucket_elems and self._hi - lo >= self.tail_min_elems:
+            self._launch(lo, self._hi, after)
+            self._hi = lo
 
     def finish(self, after=()):
         if self.world == 1 and not self._force:
