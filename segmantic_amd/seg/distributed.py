@@ -49,7 +49,8 @@ class GradSync:
     ``ready(lo)`` is called by the engine when every gradient at arena offset >= lo is final.
     Buckets are cut from the end of the arena (backward order); each is reduced on a side
     stream as soon as it is complete.  ``finish()`` makes the compute stream wait for all of
-    them.  Bucket size: the whole 19 MB arena fits ~5 buckets of 4 MiB; on xGMI (point-to-point
+    them.  Bucket size: the 19 MB arena of the benchmark network goes out as 4 buckets of 4 MiB + the
+    tail (1.3 / 0.85 / 0.2 MiB as the down path finishes, 30 KiB at finish()); on xGMI (point-to-point
     links) fewer, larger messages are per-link-bound rather than latency-bound.
     """
 
