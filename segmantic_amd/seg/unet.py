@@ -611,6 +611,10 @@ class UNetEngine:
         # concurrently with the dgrad / BatchNorm-backward chain of the main stream (the
         # mid / deep levels do not fill 256 CUs with one kernel at a time).  All wgrads share the
         # side stream, hence also their scratch buffer, in issue order.
+        if self._defer_open:
+            # issued later, when the main chain is down in the small deep levels (see defer_top_wgrad)
+            self._deferred.append((conv, x, dy, need_bias, in_tf))
+            return
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else None
         if side is not None:
@@ -916,6 +920,15 @@ class UNetEngine:
             self._ru_fwd_eval(lvl["upru"], au, out)
 
     def _level_bwd(self, lvl, dout, dx=None, extra=None):
+        if self._defer_open and self._bwd_depth >= self.defer_flush_depth:
+            self._flush_deferred()
+        self._bwd_depth += 1
+        try:
+            self._level_bwd_body(lvl, dout, dx, extra)
+        finally:
+            self._bwd_depth -= 1
+
+    def _level_bwd_body(self, lvl, dout, dx=None, extra=None):
         p = lvl["prefix"]
         sv = self._saved[p + "up"]
         cat, u = sv["cat"], sv["u"]
@@ -1038,7 +1051,15 @@ class UNetEngine:
                 full = self._bufs["dlogits"]
                 full[..., :dlogits.shape[4]].copy_(dlogits)
             dlogits = full
-        self._level_bwd(self.levels, dlogits)
+        self._deferred = []
+        self._defer_open = self.defer_top_wgrad and self.grad_hook is None and self.overlap_wgrad
+        self._bwd_depth = 0
+        try:
+            self._level_bwd(self.levels, dlogits)
+            if self._defer_open:                 # a net shallower than the flush depth
+                self._flush_deferred()
+        finally:
+            self._defer_open = False
         self._top_bias_conv = None
         self._join_side()
 
@@ -1083,6 +1104,35 @@ class UNetEngine:
     # BatchNorm-backward reduction in the epilogue of the input-gradient launch that produces its
     # operand (segmi_bn_bwd_sums); SEGMI_FUSE_BN_BWD=0 keeps the separate two-tensor pass (A/B)
     fuse_bn_bwd = os.environ.get("SEGMI_FUSE_BN_BWD", "1") != "0"
+    # Single-GPU training: the weight gradients of the decoder levels above the deepest one (among them
+    # the persistent wgrad_ws launches of the two full-resolution levels, ~0.7 ms) are ISSUED only when
+    # the main chain enters the deepest level: beside the big bandwidth-bound input-gradient /
+    # BatchNorm-backward kernels of the upper levels they only take CUs and fabric away, beside the
+    # latency-bound 16^3 / 8^3 kernels they fill an idle chip.  5.64-5.72 vs 5.69-5.77 ms per step
+    # (alternating runs, one box; flushing one level earlier: no gain, at the very end: 6.2 ms).
+    # Not with a grad_hook (data parallel): the arena suffix would become final later and every gradient
+    # bucket with it.  SEGMI_DEFER_TOP_WGRAD=0 issues every weight gradient as soon as its operands exist;
+    # SEGMI_DEFER_DEPTH overrides the level at which the queue is flushed.
+    defer_top_wgrad = os.environ.get("SEGMI_DEFER_TOP_WGRAD", "1") != "0"
+    _defer_depth_env = os.environ.get("SEGMI_DEFER_DEPTH")
+
+    @property
+    def defer_flush_depth(self) -> int:
+        if self._defer_depth_env is not None:
+            return int(self._defer_depth_env)
+        depth, lvl = 0, self.levels
+        while lvl.get("sub") is not None:
+            depth, lvl = depth + 1, lvl["sub"]
+        return depth                                  # index of the deepest level
+    _defer_open = False
+    _deferred: list = []
+    _bwd_depth = 0
+
+    def _flush_deferred(self):
+        self._defer_open = False
+        todo, self._deferred = self._deferred, []
+        for conv, x, dy, need_bias, in_tf in todo:
+            self._wgrad(conv, x, dy, need_bias=need_bias, in_tf=in_tf)
     _side2 = None
 
     def _fork_branch(self):
