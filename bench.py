@@ -36,11 +36,15 @@ import statistics
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# the HIP runtime reads this when it initialises: set before anything can touch the GPU (the package
+# import sets it too; an exported value wins).  See segmantic_amd/seg/launch.py.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X dense (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0
@@ -231,8 +235,7 @@ def make_net(K, size, precision, device):
 def run_train(args, precision, rank, world, device, barrier, steps, warmup):
     K = args.classes
     net = make_net(K, args.size, precision, device).train()
-    if world > 1:
-        net.enable_grad_sync()
+    gs = net.enable_grad_sync() if world > 1 else None
     img, lab = synthetic(args.batch, args.size, K, rank, device)
     batch = {"image": img, "label": lab}
     for _ in range(warmup):
@@ -241,6 +244,8 @@ def run_train(args, precision, rank, world, device, barrier, steps, warmup):
     key = top_conv(eng).prefix + ":fwd"
     eng.timed = {key}
     eng.timings.clear()
+    if gs is not None:
+        gs.measure = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -248,24 +253,32 @@ def run_train(args, precision, rank, world, device, barrier, steps, warmup):
     barrier()
     dt = time.perf_counter() - t0
     eng.timed = None
+    exposed = statistics.mean(gs.exposed_ms()) if gs is not None and gs.exposed_events else None
     vox = args.batch * args.size ** 3
     roof = roofline_of_top_conv(eng, key, vox, precision, eng._bufs["logits.t"]) if rank == 0 else None
     fpv = conv_flops_per_voxel(eng, True)
-    return {"dt": dt, "units": vox * steps, "roofline": roof, "step_conv_flops": vox * fpv, "net": net}
+    return {"dt": dt, "units": vox * steps, "roofline": roof, "step_conv_flops": vox * fpv, "net": net,
+            "exposed_allreduce_ms": exposed, "grad_bytes": eng.flat_grad.numel() * 4}
 
 
-def run_infer(args, rank, device, barrier, steps, warmup):
-    from segmantic_amd.seg.inferers import group_factor, sliding_window_inference, window_starts
+def run_infer(args, rank, device, barrier, steps, warmup, lanes=None, net=None, vol=None, z_slab=None):
+    """``lanes``: streams the window groups alternate over (None = the library default)."""
+    from segmantic_amd.seg.inferers import (default_lanes, group_factor, sliding_window_inference,
+                                            window_starts)
     K, V = args.classes, args.volume
     per_launch = args.sw_batch * group_factor()      # windows per forward of OUR network (inferers.py)
-    net = make_net(K, args.size, args.precision, device).eval()
-    g = torch.Generator().manual_seed(99 + rank)
-    vol = torch.randn((1, 1, V, V, V), generator=g).to(device)
+    if net is None:
+        net = make_net(K, args.size, args.precision, device).eval()
+    if vol is None:
+        g = torch.Generator().manual_seed(99 + (0 if z_slab is not None else rank))
+        vol = torch.randn((1, 1, V, V, V), generator=g).to(device)
+    st = {}
 
-    def run():
+    def run(stats=None):
         with torch.no_grad():
             return sliding_window_inference(vol, (args.size,) * 3, args.sw_batch, net, overlap=args.overlap,
-                                            return_labels=True, return_logits=False)
+                                            return_labels=True, return_logits=False, lanes=lanes,
+                                            z_slab=z_slab, stats=stats)
     for _ in range(warmup):
         run()
     eng = net._engine
@@ -275,21 +288,27 @@ def run_infer(args, rank, device, barrier, steps, warmup):
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        run()
+        res = run(st)
     barrier()
     dt = time.perf_counter() - t0
     eng.timed = None
+    lane_busy = [sum(a.elapsed_time(b) for a, b in evs) / steps for evs in st.get("lane_events", [])]
     nwin = len(window_starts((V,) * 3, (args.size,) * 3, args.overlap))
     xa = torch.empty((per_launch, args.size, args.size, args.size, eng.kpad), dtype=eng.dtype, device=device)
     roof = roofline_of_top_conv(eng, key, per_launch * args.size ** 3, args.precision, xa, full_only=True)
     del xa
+    nl = st.get("lanes", lanes or default_lanes())
     if roof:
         roof["kernel"] += (f"; {per_launch} windows per launch (sw_batch {args.sw_batch} x internal group "
-                           f"{group_factor()}), {nwin} windows per volume, two window groups in flight on two streams; "
-                           f"average over the full-size launches (the ragged last group of a volume is left out)")
+                           f"{group_factor()}), {nwin} windows per volume, window groups alternating over {nl} "
+                           f"stream(s); average over the full-size launches (the ragged last group of a volume is "
+                           f"left out)")
     fpv = conv_flops_per_voxel(eng, False)
-    return {"dt": dt, "steps": steps, "roofline": roof, "windows": nwin,
-            "conv_TFLOP_per_volume": nwin * args.size ** 3 * fpv / 1e12}
+    return {"dt": dt, "steps": steps, "roofline": roof, "windows": nwin, "lanes": nl,
+            "lane_busy_ms_per_volume": lane_busy,
+            "host_enqueue_ms_per_volume": st.get("host_enqueue_s", 0.0) / steps * 1e3,
+            "conv_TFLOP_per_volume": nwin * args.size ** 3 * fpv / 1e12, "net": net, "vol": vol,
+            "labels": res.labels}
 
 
 def run_fit(args, rank, device, barrier, steps, warmup):
@@ -337,10 +356,16 @@ def run_fit(args, rank, device, barrier, steps, warmup):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as children of this process
+        # (which has not touched the GPU and never will), let rank 0 print the JSON line on the
+        # inherited stdout, exit with the launcher's code.  What pl.Trainer(devices=N) does for the
+        # reference (monai_unet.py:529-538).
+        from segmantic_amd.seg import launch
+        raise SystemExit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    import segmantic_amd
     from segmantic_amd.seg.distributed import init_distributed
     rank, local_rank, world = init_distributed()
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
@@ -378,6 +403,13 @@ def main():
                           "labels": K, "parallelism": f"dp{world}",
                           "step_conv_TFLOPs": r["step_conv_flops"] / 1e12,
                           "whole_step_TFLOP_per_s_per_gpu": r["step_conv_flops"] / (dt / args.steps) / 1e12}}
+        if world > 1:
+            out["config"]["gradient_exchange"] = {
+                "bytes_per_step": r["grad_bytes"], "buckets": "4 MiB from the end of the arena + tail rule",
+                "backend": torch.distributed.get_backend(),
+                "exposed_allreduce_ms_per_step_rank0": r["exposed_allreduce_ms"],
+                "what": "time the training stream waits in GradSync.finish() after backward has ended (HIP events); "
+                        "the rest of the exchange ran under backward on the side stream"}
         if rank == 0 and r["roofline"]:
             r["roofline"]["traffic"] = pmc_traffic("train_top_conv_fwd_hbm_bytes_per_launch") \
                 if (args.precision, args.batch, args.size, K) == ("bf16", 8, 128, 16) else None
@@ -394,10 +426,25 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
     if wl in ("all", "infer"):
         try:
-            r = run_infer(args, rank, device, barrier, args.infer_steps if wl == "all" else args.steps,
-                          1 if wl == "all" else args.warmup)
-            dt = maxdt(r["dt"])
+            from segmantic_amd.seg.inferers import default_lanes
+            isteps = args.infer_steps if wl == "all" else args.steps
+            iwarm = 1 if wl == "all" else args.warmup
             V = args.volume
+            # the library default first (headline), then the other lane count on the same network and
+            # volume: the line carries both, so a box where two lanes alias one hardware queue shows it
+            dl = default_lanes()
+            r = run_infer(args, rank, device, barrier, isteps, iwarm, lanes=dl)
+            dt = maxdt(r["dt"])
+            other = 1 if dl > 1 else 2
+            r2 = run_infer(args, rank, device, barrier, isteps, 1, lanes=other, net=r["net"], vol=r["vol"])
+            dt2 = maxdt(r2["dt"])
+            same = bool(torch.equal(r["labels"], r2["labels"]))
+
+            def lane_fig(rr, d):
+                return {"lanes": rr["lanes"], "value": rr["steps"] * world / d, "ms_per_volume": d / rr["steps"] * 1e3,
+                        "lane_busy_ms_per_volume": rr["lane_busy_ms_per_volume"],
+                        "host_enqueue_ms_per_volume": rr["host_enqueue_ms_per_volume"],
+                        "top_conv_avg_launch_ms": rr["roofline"]["avg_launch_ms"] if rr["roofline"] else None}
             inf = {"metric": "sliding-window infer vols/s", "value": r["steps"] * world / dt, "unit": "volumes/s",
                    "steps": r["steps"], "ms_per_volume": dt / r["steps"] * 1e3, "dtype": args.precision,
                    "config": {"workload": f"sliding_window_inference of one {V}^3 volume, roi {args.size}^3, overlap "
@@ -406,10 +453,34 @@ def main():
                               "conv_TFLOP_per_volume": r["conv_TFLOP_per_volume"],
                               "conv_TFLOP_per_s": r["conv_TFLOP_per_volume"] * r["steps"] / dt,
                               "parallelism": f"replicas{world}"},
+                   "lanes": {"default": dl, "figures": [lane_fig(r, dt), lane_fig(r2, dt2)],
+                             "labels_identical": same,
+                             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                             "hw_queues_set_before_runtime_init": bool(segmantic_amd.HW_QUEUES_EFFECTIVE),
+                             "streams_created_before_this_leg": "training + weight-gradient (train leg of this run)"
+                             if wl == "all" else "none"},
                    "roofline": r["roofline"]}
             if inf["roofline"]:
                 inf["roofline"]["traffic"] = pmc_traffic("infer_top_conv_fwd_hbm_bytes_per_launch")
-            del r
+            if world > 1:
+                # ONE volume cut into z-slabs (north_star's inference split): every rank runs the windows
+                # that touch its slab, the only exchange is the all-gather of the 1-byte label slabs
+                from segmantic_amd.seg.inferers import gather_label_slabs, z_slabs
+                slab = z_slabs(V, world)[rank]
+                rs = run_infer(args, rank, device, barrier, isteps, 1, lanes=dl, net=r["net"], z_slab=slab)
+                barrier()
+                t0 = time.perf_counter()
+                full = gather_label_slabs(rs["labels"][0, 0], V, rank, world)
+                barrier()
+                tg = maxdt(time.perf_counter() - t0)
+                dts = maxdt(rs["dt"])
+                inf["one_volume_sharded"] = {
+                    "what": f"one {V}^3 volume cut into {world} z-slabs, one per rank; label slabs all-gathered",
+                    "value": rs["steps"] / (dts + tg * rs["steps"]), "unit": "volumes/s",
+                    "ms_per_volume": (dts / rs["steps"] + tg) * 1e3, "label_allgather_ms": tg * 1e3,
+                    "labels_shape": list(full.shape)}
+                del rs, full
+            del r, r2
             torch.cuda.empty_cache()
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 try:

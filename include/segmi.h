@@ -309,7 +309,8 @@ int segmi_label_counts(const int32_t* pred, const int32_t* truth, int64_t n, int
  * continuous input index (x,y,z).  pixel: 0=f32 1=u8 2=i16 3=i32 4=u16.  Arrays are [z][y][x].
  * interp: 0 = linear, 1 = nearest (outside the input buffer -> default_value, as ITK); +2 = border
  * padding: the continuous index is clamped to the buffer first (MONAI Spacingd's padding_mode=
- * "border", monai_unet.py:173-174 and its inverse under Invertd, :615-621). */
+ * "border", monai_unet.py:173-174 and its inverse under Invertd, :615-621); +4 (with 1 only) =
+ * nearest rounds x.5 to the even index (torch grid_sample / MONAI mode="nearest") instead of up (ITK). */
 int segmi_resample3d(int pixel, const void* src, int sx, int sy, int sz, void* dst, int dx,
                      int dy, int dz, const double* index_map_host, int interp,
                      double default_value, void* stream);

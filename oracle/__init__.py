@@ -19,6 +19,7 @@ A plain torch-CPU / numpy fp32 restatement of the arithmetic that the reference
                     channel_wise=True)`` (``:164``).
 * ``resample_ref``  ITK ``ResampleImageFilter`` semantics used by
                     ``src/segmantic/image/processing.py:49-120``.
+* ``ensemble_ref``  ``SelectBestEnsemble`` of ``src/segmantic/seg/transforms.py:15-61``.
 
 Third-party dependencies that hold the algorithm (all absent from ``/root/reference`` and from
 this image, all *unpinned* in the reference's ``pyproject.toml:24-40``): ``monai`` (code needs
@@ -40,4 +41,8 @@ What *is* pinned against the reference / its dependencies' published facts:
 * ``resample`` output geometry asserted by the reference's ``tests/image/test_image.py:33-52``.
 * ``Net`` hparams of ``tests/seg/test_unet.py:15-20``; config round trips of
   ``tests/utils/test_cli.py:19-80``.
+* ``ensemble_ref.ref_select_best`` (``SelectBestEnsemble``, ``seg/transforms.py:39-61``): the one
+  value-level vector the reference's tests hold for this path, ``tests/seg/test_transforms.py:9-43``
+  (label and one-hot forms), committed as ``tests/golden/reference_select_best.json`` -- this
+  function, and through it ``ops.ensemble_select``, is **pinned**.
 """

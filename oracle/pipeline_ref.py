@@ -188,13 +188,24 @@ def ref_trilinear_border(vol: np.ndarray, xform: np.ndarray, out_shape) -> np.nd
     return out.reshape((C,) + tuple(int(v) for v in out_shape)).astype(np.float32)
 
 
-def ref_spacing(vol: np.ndarray, affine: np.ndarray, pixdim: Sequence[float]):
+def ref_nearest_border(vol: np.ndarray, xform: np.ndarray, out_shape) -> np.ndarray:
+    """``mode="nearest"`` of the same resampler: torch ``grid_sample`` takes ``nearbyint`` of the
+    (border-clamped) source coordinate -- round half to even, ``np.rint``."""
+    n = np.asarray(vol.shape[1:])
+    idx = np.indices(tuple(int(v) for v in out_shape)).reshape(3, -1).astype(np.float64)
+    src = xform[:3, :3] @ idx + xform[:3, 3:4]
+    ii = [np.clip(np.rint(np.clip(src[d], 0.0, n[d] - 1.0)).astype(np.int64), 0, n[d] - 1) for d in range(3)]
+    return vol[:, ii[0], ii[1], ii[2]].reshape((vol.shape[0],) + tuple(int(v) for v in out_shape)).astype(np.float32)
+
+
+def ref_spacing(vol: np.ndarray, affine: np.ndarray, pixdim: Sequence[float], nearest: bool = False):
     """MONAI ``Spacing(pixdim)`` forward: (resampled [C,...] float32, new affine)."""
     new_affine = ref_zoom_affine(affine, pixdim)
     out_shape, offset = ref_compute_shape_offset(vol.shape[1:], affine, new_affine)
     new_affine[:3, 3] = offset
     xform = np.linalg.solve(np.asarray(affine, np.float64), new_affine)
-    return ref_trilinear_border(vol, xform, out_shape), new_affine
+    fn = ref_nearest_border if nearest else ref_trilinear_border
+    return fn(vol, xform, out_shape), new_affine
 
 
 def ref_spacing_inverse(vol: np.ndarray, cur_affine: np.ndarray, orig_affine: np.ndarray, orig_shape):

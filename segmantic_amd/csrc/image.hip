@@ -43,7 +43,11 @@ __global__ void resample_kernel(ResampleParams p) {
                         cz >= -0.5 && cz < p.sz - 0.5;
     if (inside) {
       if (p.interp & 1) {
-        int ix = (int)floor(cx + 0.5), iy = (int)floor(cy + 0.5), iz = (int)floor(cz + 0.5);
+        // ITK rounds half up; bit 4 = round half to even (torch grid_sample "nearest" = nearbyint,
+        // what MONAI's Spacing(mode="nearest") ends in)
+        int ix, iy, iz;
+        if (p.interp & 4) { ix = (int)rint(cx); iy = (int)rint(cy); iz = (int)rint(cz); }
+        else { ix = (int)floor(cx + 0.5); iy = (int)floor(cy + 0.5); iz = (int)floor(cz + 0.5); }
         ix = ix < 0 ? 0 : (ix > p.sx - 1 ? p.sx - 1 : ix);
         iy = iy < 0 ? 0 : (iy > p.sy - 1 ? p.sy - 1 : iy);
         iz = iz < 0 ? 0 : (iz > p.sz - 1 ? p.sz - 1 : iz);
@@ -134,7 +138,8 @@ int segmi_resample3d(int pixel, const void* src, int sx, int sy, int sz, void* d
                      double default_value, void* stream) {
   SEGMI_CHECK_ARG(src && dst && index_map_host, "resample3d: null pointer");
   SEGMI_CHECK_ARG(sx > 0 && sy > 0 && sz > 0 && dx > 0 && dy > 0 && dz > 0, "resample3d: empty image");
-  SEGMI_CHECK_ARG(interp >= 0 && interp <= 3, "resample3d: interp must be 0 (linear) or 1 (nearest), +2 for border padding");
+  SEGMI_CHECK_ARG(interp >= 0 && interp <= 7 && (!(interp & 4) || (interp & 1)),
+                  "resample3d: interp must be 0 (linear) or 1 (nearest), +2 for border padding, +4 (nearest only) to round half to even");
   ResampleParams p{};
   p.src = src; p.dst = dst; p.sx = sx; p.sy = sy; p.sz = sz; p.dx = dx; p.dy = dy; p.dz = dz;
   for (int i = 0; i < 12; ++i) p.m[i] = index_map_host[i];

@@ -412,11 +412,15 @@ def sw_gather(image, img_index, starts, windows) -> None:
 
 
 def sw_scatter_add(pred, starts, acc, cnt, importance=None) -> None:
-    a, b = act(pred), act(acc)
-    arr, p = _starts(starts, 3)
-    check(lib.segmi_sw_scatter_add(dtype_code(pred), C.byref(a), p, arr.shape[0],
-                                   _ptr(importance), C.byref(b), _ptr(cnt), _stream()),
-          "sw_scatter_add")
+    b = act(acc)
+    # larger groups: one launch per 16 windows, in schedule order (launches on one stream run in
+    # order, so every voxel still receives its windows in the reference's sequence)
+    for i in range(0, len(starts), SW_MAX_WINDOWS):
+        arr, p = _starts(starts[i:i + SW_MAX_WINDOWS], 3)
+        a = act(pred[i:i + arr.shape[0]])
+        check(lib.segmi_sw_scatter_add(dtype_code(pred), C.byref(a), p, arr.shape[0],
+                                       _ptr(importance), C.byref(b), _ptr(cnt), _stream()),
+              "sw_scatter_add")
 
 
 _LABEL_BYTES = {torch.uint8: 1, torch.int16: 2, torch.int32: 4}
@@ -464,10 +468,12 @@ def label_counts(pred, truth, k, counts) -> None:
 _PIXEL = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.int32: 3, torch.uint16: 4}
 
 
-def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, default=0.0, border=False):
+def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, default=0.0, border=False,
+               half_even=False):
     """src [z,y,x] -> dst [z,y,x]; index_map: 3x4 out-index(x,y,z,1) -> in-index(x,y,z).
     ``border``: clamp the continuous index to the buffer (MONAI ``padding_mode="border"``) instead
-    of ITK's default-pixel-outside rule."""
+    of ITK's default-pixel-outside rule.  ``half_even`` (nearest only): round x.5 to the even index
+    (torch ``grid_sample`` / MONAI) instead of up (ITK)."""
     _require_device(src)
     if src.dim() != 3 or not src.is_contiguous():
         raise ValueError("resample3d expects a contiguous [z,y,x] tensor")
@@ -476,7 +482,7 @@ def resample3d(src: torch.Tensor, out_size_zyx, index_map, nearest=False, defaul
     m = np.ascontiguousarray(np.asarray(index_map, dtype=np.float64).reshape(12))
     sz, sy, sx = src.shape
     check(lib.segmi_resample3d(_PIXEL[src.dtype], _ptr(src), sx, sy, sz, _ptr(dst), dx, dy, dz,
-                               m.ctypes.data_as(C.c_void_p), (1 if nearest else 0) | (2 if border else 0),
+                               m.ctypes.data_as(C.c_void_p), (1 if nearest else 0) | (2 if border else 0) | (4 if nearest and half_even else 0),
                                float(default), _stream()), "resample3d")
     return dst
 

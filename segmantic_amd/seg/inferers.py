@@ -78,11 +78,19 @@ class SlidingWindowResult:
 _LANES: dict = {}
 
 
-def _lane_streams(device):
-    """Two streams for alternating window groups (SEGMI_SW_LANES=1 keeps everything on the current
-    stream, e.g. for per-kernel profiling)."""
-    n = int(os.environ.get("SEGMI_SW_LANES", "2"))
-    if n < 2 or os.environ.get("SEGMI_SERIAL"):
+def default_lanes() -> int:
+    """Streams that window groups alternate over when the predictor is this build's own network
+    (SEGMI_SW_LANES; 1 = everything on the caller's stream)."""
+    if os.environ.get("SEGMI_SERIAL"):
+        return 1
+    return max(1, int(os.environ.get("SEGMI_SW_LANES", "2")))
+
+
+def _lane_streams(device, n: Optional[int] = None):
+    """``n`` streams for alternating window groups (None: ``default_lanes()``; < 2: no side streams,
+    everything stays on the current stream, e.g. for per-kernel profiling)."""
+    n = default_lanes() if n is None else int(n)
+    if n < 2:
         return None
     key = (torch.device(device).index, n)
     if key not in _LANES:
@@ -108,7 +116,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                              return_labels: bool = False, window_dtype: Optional[torch.dtype] = None,
                              window_range: Optional[Tuple[int, int]] = None,
                              blend: str = "auto", return_logits: bool = True,
-                             z_slab: Optional[Tuple[int, int]] = None):
+                             z_slab: Optional[Tuple[int, int]] = None, lanes: Optional[int] = None,
+                             stats: Optional[dict] = None):
     """inputs [B,C,D,H,W] float32 on the GPU.  ``predictor`` maps [b,C,*roi] -> [b,K,*roi].
 
     Returns logits [B,K,D,H,W] (float32), or a ``SlidingWindowResult`` when ``return_labels``
@@ -126,13 +135,19 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     complete ordered sum: the slab is bit-identical to the same planes of the full result).  This
     is the multi-GPU form of one volume: rank r takes slab r of ``z_slabs`` and only the label
     slabs travel (``gather_label_slabs``); needs the deferred blend.
+
+    ``lanes``: number of streams the window groups alternate over (own network only; None =
+    ``default_lanes()``).  ``stats``: a dict that receives measurement hooks of this call --
+    ``host_enqueue_s`` (host time to enqueue all window groups), ``lane_events`` (per lane, one
+    (start, end) HIP-event pair per window group), ``lanes``.
     """
     if inputs.dim() == 4:          # 2-D images: run as depth-1 volumes through the same kernels
         own = hasattr(getattr(predictor, "__self__", predictor), "forward_into")
         pred3 = predictor if own else (lambda w: predictor(w.squeeze(2)).unsqueeze(2))
         res = sliding_window_inference(
             inputs.unsqueeze(2), (1,) + tuple(roi_size), sw_batch_size, pred3, overlap, mode,
-            sigma_scale, device, return_labels, window_dtype, window_range, blend, return_logits, None)
+            sigma_scale, device, return_labels, window_dtype, window_range, blend, return_logits, None,
+            lanes, stats)
         if not return_labels:
             return res.squeeze(2)
         return SlidingWindowResult(None if res.logits is None else res.logits.squeeze(2),
@@ -188,13 +203,17 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     want_logits = return_logits or not return_labels or partial
     nvox_roi = roi[0] * roi[1] * roi[2]
     outs, labs, cnts = [], [], []
-    lanes = _lane_streams(dev) if into is not None else None
+    lanes = _lane_streams(dev, lanes) if into is not None else None
+    lane_events = [[] for _ in (lanes or [None])]
+    import time as _time
+    t_enq = _time.perf_counter()
     # Window groups handed to OUR network may be larger than sw_batch_size: in eval mode every
     # window is computed independently of its batch neighbours (folded BatchNorm: the grouping can
     # only change which kernel a layer picks, i.e. the f32 summation order in front of a bf16
     # rounding), and the deep 8^3 / 16^3 layers of a 4-window forward do not fill the chip (47 us
     # per launch for 3 % of the FLOPs).  A foreign predictor callable always sees exactly
     # sw_batch_size windows, as MONAI would give it.
+    # (The streaming fallback keeps the enlarged groups: gather and scatter-add chunk them by 16.)
     if into is not None:
         sw_batch_size = int(sw_batch_size) * group_factor()
     for b in range(B):
@@ -216,20 +235,34 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                     forked = True
                 lane = gi % len(lanes)
                 with torch.cuda.stream(lanes[lane]):
+                    if stats is not None:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
                     wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
                                        device=dev)
                     ops.sw_gather(img, b, grp, wbuf)
                     ok = into(wbuf.permute(0, 4, 1, 2, 3), cache[slot:slot + len(grp)], lane)
+                    if stats is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        lane_events[lane].append((e0, e1))
                 if ok:
                     continue
                 if gi > 1:
                     raise RuntimeError("predictor stopped accepting forward_into mid-volume")
                 into = None          # e.g. a class count the cache layout cannot take directly
+            if stats is not None and lanes is None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
                                device=dev)
             ops.sw_gather(img, b, grp, wbuf)
             wview = wbuf.permute(0, 4, 1, 2, 3)
             if cache is not None and into is not None and into(wview, cache[slot:slot + len(grp)]):
+                if stats is not None and lanes is None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    lane_events[0].append((e0, e1))
                 continue                                   # predicted straight into the cache
             pn = as_ndhwc(predictor(wview))
             if K is None:                                  # first group: pick the strategy
@@ -251,6 +284,14 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         if forked:
             for st in lanes:
                 main.wait_stream(st)
+        if stats is not None:
+            stats["host_enqueue_s"] = stats.get("host_enqueue_s", 0.0) + (_time.perf_counter() - t_enq)
+            stats["lanes"] = len(lanes) if lanes else 1
+            stats.setdefault("lane_events", [[] for _ in lane_events])
+            for dst, src in zip(stats["lane_events"], lane_events):
+                dst.extend(src)
+            t_enq = _time.perf_counter()
+            lane_events = [[] for _ in lane_events]
         lab = None
         if not partial and return_labels:
             lab = torch.empty((out_d, orig[1], orig[2]),

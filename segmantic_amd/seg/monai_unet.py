@@ -20,7 +20,8 @@ import torch
 
 from .. import ops
 from ..image.labels import load_decathlon_tissuelist, load_tissue_list
-from .distributed import GradSync, broadcast_buffers, env_world, init_distributed
+from .distributed import (GradSync, broadcast_buffers, env_world, init_distributed,
+                          rank_device_index)
 from .inferers import SlidingWindowInferer, sliding_window_inference
 from .losses import (ConfusionMatrixMetric, DiceLoss, DiceMetric, as_ndhwc, dice_backward,
                      dice_forward)
@@ -73,6 +74,7 @@ class Net(torch.nn.Module):
     num_samples: int = 4
     flip_prob: float = 0.2            # RandFlipd(prob=0.2) per axis, reference :214-217
     train_spacing: list = []          # Spacingd(pixdim) of a configured training pre-processing
+    train_spacing_label_nearest: bool = False   # ... with mode=[bilinear, nearest] (label not interpolated)
     optimizer: dict = {"optimizer": "Adam", "lr": 1e-4, "momentum": 0.9, "epsilon": 1e-8,
                        "amsgrad": False, "weight_decouple": False}
     lr_scheduling: dict = {"scheduler": "Constant", "factor": 0.5, "patience": 10, "T_0": 50,
@@ -349,6 +351,23 @@ def train(
     from .dataset import PairedDataSet
     from .trainer import fit
 
+    from . import launch
+    n_ranks = len(list(gpu_ids or []))
+    if n_ranks > 1 and not launch.under_launcher():
+        # several gpu_ids: one process per GPU, started from here as children of this process --
+        # what pl.Trainer(devices=len(gpu_ids)) does for the reference (:529-538).  The parent has not
+        # touched the GPU yet and never will; it hands the call to the ranks as a train-config file.
+        call = dict(datalist=datalist, image_dir=image_dir, labels_dir=labels_dir, output_dir=output_dir,
+                    checkpoint_file=checkpoint_file, num_classes=num_classes, num_channels=num_channels,
+                    spatial_dims=spatial_dims, spatial_size=spatial_size, preprocessing=preprocessing,
+                    augmentation=augmentation, augment_intensity=augment_intensity,
+                    augment_spatial=augment_spatial, channels=channels, strides=strides, dropout=dropout,
+                    act=act, num_samples=num_samples, optimizer=optimizer, lr_scheduling=lr_scheduling,
+                    max_epochs=max_epochs, early_stop_patience=early_stop_patience,
+                    mixed_precision=mixed_precision, cache_rate=cache_rate, gpu_ids=gpu_ids,
+                    tissue_list=tissue_list)
+        return _train_in_ranks(n_ranks, call)
+
     if optimizer is None:
         optimizer = dict(Net.optimizer)
     if lr_scheduling is None:
@@ -399,11 +418,21 @@ def train(
                 raise ValueError(f"'preprocessing': the on-device pipeline always runs {missing}; add the "
                                  "corresponding transforms or leave 'preprocessing' empty")
             net.train_spacing = plan["spacing"]
+            net.train_spacing_label_nearest = bool(plan["spacing_label_nearest"])
     if augmentation:
         parser = ConfigParser({"image_key": "image", "label_key": "label", "augmentation": augmentation})
         parser.parse(True)
         plan = plan_augmentation(parser.get_parsed_content("augmentation"))
         if plan is not None:
+            if plan["num_classes"] is not None and plan["num_classes"] != net.num_classes:
+                raise ValueError(f"'augmentation': RandCropByLabelClassesd is configured for {plan['num_classes']} "
+                                 f"classes, the network has {net.num_classes}")
+            if plan["flip_axes"] and len(plan["flip_axes"]) != net.spatial_dims:
+                raise ValueError(f"'augmentation': RandFlipd entries for axes {plan['flip_axes']} but spatial_dims = "
+                                 f"{net.spatial_dims} (one entry per spatial axis)")
+            if plan.get("pad_size") is not None and plan["spatial_size"] is not None \
+                    and list(plan["pad_size"]) != list(plan["spatial_size"]):
+                raise ValueError("'augmentation': SpatialPadd and RandCropByLabelClassesd must share one spatial_size")
             net.num_samples = plan["num_samples"]
             net.flip_prob = plan["flip_prob"]
             net.augment_spatial = net.augment_spatial or plan["augment_spatial"]
@@ -415,6 +444,11 @@ def train(
     net.cache_rate = cache_rate
     net.mixed_precision = bool(mixed_precision)
 
+    # process group first: nothing above has made a device call (the runtime environment was set when
+    # the package was imported), and init_distributed() binds the rank to its GPU before the first one
+    rank, local_rank, world = env_world()
+    if world > 1:
+        init_distributed(device_index=rank_device_index(gpu_ids, local_rank))
     if not torch.cuda.is_available():
         raise RuntimeError(
             "segmantic_amd.train needs an MI355X: torch.cuda.is_available() is False and there "
@@ -422,10 +456,8 @@ def train(
             "reference itself)")
     output_dir = Path(output_dir)
     output_dir.mkdir(exist_ok=True, parents=True)
-    rank, _, world = env_world()
     if world > 1:                         # one process per GPU: every rank trains on rank 0's split
         from .trainer import sync_dataset
-        init_distributed()
         net.dataset = sync_dataset(net.dataset)
     if rank == 0:
         (output_dir / "Dataset.json").write_text(net.dataset.dump_dataset())
@@ -433,6 +465,57 @@ def train(
         gpu_ids=gpu_ids, ckpt_name=_ckpt_name)
     print(f"train completed, best_metric: {net.best_val_dice:.4f} at epoch {net.best_val_epoch}")
     return net
+
+
+def _train_in_ranks(n_ranks: int, call: dict) -> Optional[Net]:
+    """Run ``train(**call)`` as ``n_ranks`` processes (one per entry of ``gpu_ids``) and return the
+    best checkpoint's network (on the CPU; None when no checkpoint was written).  The call travels
+    as a train-config file: the config schema IS the signature (reference ``:400-428``)."""
+    import inspect
+    import tempfile
+
+    from ..utils import config
+    from ..utils.cli import cast_from_path
+    from . import launch
+    sig = inspect.signature(train)
+    out = Path(call["output_dir"])
+    out.mkdir(exist_ok=True, parents=True)
+    plain = {}
+    for k, v in call.items():
+        v = cast_from_path(v, sig.parameters[k])
+        plain[k] = list(v) if isinstance(v, tuple) else v
+    with tempfile.NamedTemporaryFile("w", suffix=".json", prefix="ranks_", dir=str(out), delete=False) as f:
+        f.write(config.dumps(plain, is_json=True))
+        cfg = f.name
+    try:
+        rc = launch.spawn_ranks(n_ranks, ["-m", "segmantic_amd.commands.monai_unet_cli", "train-config", "-c", cfg])
+    finally:
+        os.unlink(cfg)
+    if rc != 0:
+        raise RuntimeError(f"segmantic_amd.train: the {n_ranks}-rank launch exited with code {rc}")
+    best = None
+    for p in out.glob("epoch=*-val_dice=*.ckpt"):
+        m = re.search(r"val_dice=([0-9.]+?)\.ckpt$", p.name)
+        if m and (best is None or float(m.group(1)) > best[0]):
+            best = (float(m.group(1)), p)
+    return Net.load_from_checkpoint(best[1]) if best else None
+
+
+def _predict_in_ranks(n_ranks: int, call: dict) -> None:
+    """``predict(**call)`` as one process per GPU (volumes dealt round-robin, rank 0 writes the tables)."""
+    import pickle
+    import tempfile
+
+    from . import launch
+    with tempfile.NamedTemporaryFile("wb", suffix=".pkl", prefix="predict_", delete=False) as f:
+        pickle.dump(call, f)
+        path = f.name
+    try:
+        rc = launch.spawn_ranks(n_ranks, ["-m", "segmantic_amd.seg.monai_unet", "--predict-call", path])
+    finally:
+        os.unlink(path)
+    if rc != 0:
+        raise RuntimeError(f"segmantic_amd.predict: the {n_ranks}-rank launch exited with code {rc}")
 
 
 def predict(
@@ -453,8 +536,15 @@ def predict(
     reproduced: the per-volume ``*_confusion.png`` plots (matplotlib; out of scope).
     The class-Dice tables are headed by the K-1 foreground tissue names (the reference prints all K
     names over the K-1 foreground values, one column off)."""
+    from . import launch
     from .pipeline import PredictPipeline
 
+    if len(list(gpu_ids or [])) > 1 and not launch.under_launcher():
+        # several gpu_ids: the volumes are independent objects -- one process per GPU, started here
+        return _predict_in_ranks(len(gpu_ids), dict(
+            model_file=model_file, test_images=test_images, test_labels=test_labels, output_dir=output_dir,
+            tissue_dict=tissue_dict, channels=channels, strides=strides, dropout=dropout, spacing=spacing,
+            gpu_ids=gpu_ids))
     model_file = Path(model_file)
     settings_json = model_file.with_suffix(".json")
     if settings_json.exists():
@@ -480,9 +570,8 @@ def predict(
     # to the ranks, no data-path collective; rank 0 collects the per-volume scores at the end
     rank, local_rank, world = env_world()
     if world > 1:
-        init_distributed()
-        ids = list(gpu_ids) if gpu_ids else list(range(torch.cuda.device_count()))
-        device = torch.device(f"cuda:{ids[local_rank % len(ids)]}")
+        device = torch.device(f"cuda:{rank_device_index(gpu_ids, local_rank)}")
+        init_distributed(device_index=device.index)
         torch.cuda.set_device(device)
     else:
         device = make_device(gpu_ids)
@@ -738,3 +827,13 @@ def ensemble_creator(
             if output_dir:
                 saved.append(pipe.save(label_vol, item, output_dir))
     return saved
+
+
+if __name__ == "__main__":      # rank entry of _predict_in_ranks
+    import pickle
+    import sys
+    if len(sys.argv) == 3 and sys.argv[1] == "--predict-call":
+        with open(sys.argv[2], "rb") as _f:
+            predict(**pickle.load(_f))
+    else:
+        raise SystemExit("usage: python -m segmantic_amd.seg.monai_unet --predict-call FILE")

@@ -111,7 +111,7 @@ def spacing_geometry(affine: np.ndarray, shape: Sequence[int], pixdim: Sequence[
 
 
 def affine_resample(vol: torch.Tensor, src_affine: np.ndarray, dst_affine: np.ndarray,
-                    dst_shape: Sequence[int]) -> torch.Tensor:
+                    dst_shape: Sequence[int], nearest: bool = False) -> torch.Tensor:
     """MONAI ``SpatialResample`` (bilinear, border padding): destination voxel i reads the source
     at continuous index ``inv(src_affine) @ dst_affine @ i`` (the ``align_corners`` flag cancels
     between MONAI's index normalisation and ``grid_sample``, see ``oracle/pipeline_ref.py``).
@@ -123,25 +123,28 @@ def affine_resample(vol: torch.Tensor, src_affine: np.ndarray, dst_affine: np.nd
         for c in range(3):
             m[r, c] = X[2 - r, 2 - c]
         m[r, 3] = X[2 - r, 3]
-    outs = [ops.resample3d(vol[c].contiguous(), list(dst_shape), m, nearest=False, border=True)
+    outs = [ops.resample3d(vol[c].contiguous(), list(dst_shape), m, nearest=nearest, border=True, half_even=True)
             for c in range(vol.shape[0])]
     return torch.stack(outs)
 
 
-def spacing_resample(vol: torch.Tensor, affine: np.ndarray, pixdim: Sequence[float]):
-    """``Spacingd(pixdim)`` forward (reference ``monai_unet.py:173-174``): (volume, new affine)."""
+def spacing_resample(vol: torch.Tensor, affine: np.ndarray, pixdim: Sequence[float], nearest: bool = False):
+    """``Spacingd(pixdim)`` forward (reference ``monai_unet.py:173-174``): (volume, new affine).
+    ``nearest``: a configured ``mode="nearest"`` for this key (the reference default is bilinear)."""
     new_affine, new_shape = spacing_geometry(affine, vol.shape[1:], pixdim)
-    return affine_resample(vol, affine, new_affine, new_shape), new_affine
+    return affine_resample(vol, affine, new_affine, new_shape, nearest=nearest), new_affine
 
 
 # ---------------------------------------------------------------------------- pipeline
 class PredictPipeline:
     """default_preprocessing + the inversion chain of ``predict`` (one volume at a time)."""
 
-    def __init__(self, device, spacing: Sequence[float] = (), with_label: bool = False):
+    def __init__(self, device, spacing: Sequence[float] = (), with_label: bool = False,
+                 label_nearest: bool = False):
         self.device = torch.device(device)
         self.spacing = list(spacing) if spacing else []
         self.with_label = with_label
+        self.label_nearest = bool(label_nearest)       # Spacingd(mode=[bilinear, nearest]) from a bundle config
 
     # -- forward chain ----------------------------------------------------------------------
     def _load(self, path) -> tuple:
@@ -182,8 +185,8 @@ class PredictPipeline:
         item["shape_crop"] = tuple(img.shape[1:])
         if self.spacing:
             img, A2 = spacing_resample(img, A, self.spacing)
-            if lab is not None:   # the reference resamples the label with the same (bilinear) mode
-                lab, _ = spacing_resample(lab, A, self.spacing)
+            if lab is not None:   # the reference's default resamples the label with the same (bilinear) mode
+                lab, _ = spacing_resample(lab, A, self.spacing, nearest=self.label_nearest)
             item["affine"] = A2
         item["image"] = img
         if lab is not None:

@@ -35,8 +35,8 @@ class CachedVolumes:
     sampler stream + one pinned D2H copy: the training stream is never synchronised by the
     sampler (a ``.cpu()`` on the training stream would drain the whole step pipeline)."""
 
-    def __init__(self, files, device, num_classes: int, spacing=()):
-        pipe = PredictPipeline(device=device, spacing=spacing, with_label=True)
+    def __init__(self, files, device, num_classes: int, spacing=(), label_nearest: bool = False):
+        pipe = PredictPipeline(device=device, spacing=spacing, with_label=True, label_nearest=label_nearest)
         self.items = []
         self.device = torch.device(device)
         self._stream = torch.cuda.Stream(device=self.device)
@@ -352,11 +352,13 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
         ckpt_name: Callable, batch_volumes: int = 2, seed: int = 0):
     if len(list(gpu_ids or [0])) > 1 and env_world()[2] == 1:
         raise RuntimeError(
-            "segmantic_amd: several gpu_ids need one process per GPU: launch with "
+            "segmantic_amd: several gpu_ids need one process per GPU: call monai_unet.train() / the "
+            "segmantic-unet CLI (they start the ranks themselves, seg/launch.py) or launch with "
             "`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ...`")
-    rank, local_rank, world = init_distributed()
     ids = list(gpu_ids) if gpu_ids else [0]
+    _r, local_rank, world = env_world()
     dev_index = ids[local_rank % len(ids)] if world > 1 else ids[0]
+    rank, local_rank, world = init_distributed(device_index=dev_index)
     device = torch.device(f"cuda:{dev_index}")
     torch.cuda.set_device(device)
     net.to(device)
@@ -371,8 +373,9 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
     print(f"[rank {rank}/{world}] caching data on {device} "
           f"({len(net.dataset.training_files())} train / {len(net.dataset.validation_files())} val volumes)")
     spacing = list(getattr(net, "train_spacing", []) or [])
-    train_cache = CachedVolumes(net.dataset.training_files(), device, net.num_classes, spacing)
-    val_cache = CachedVolumes(net.dataset.validation_files(), device, net.num_classes, spacing)
+    ln = bool(getattr(net, "train_spacing_label_nearest", False))
+    train_cache = CachedVolumes(net.dataset.training_files(), device, net.num_classes, spacing, ln)
+    val_cache = CachedVolumes(net.dataset.validation_files(), device, net.num_classes, spacing, ln)
 
     prefetch = BatchPrefetcher(net, train_cache)
 

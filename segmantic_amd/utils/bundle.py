@@ -146,11 +146,86 @@ def _check(comp, allowed, what):
     return flat
 
 
+# ---------------------------------------------------------------------------------------------
+# Keyword whitelists.  The device pipeline is FIXED (seg/pipeline.py, seg/trainer.py, seg/augment.py):
+# a configured transform is accepted only if every keyword it carries is known AND has the value the
+# device pipeline implements; anything else raises, naming the transform and the keyword -- a config
+# must never silently train with a different pipeline than the one it spells out.
+# ---------------------------------------------------------------------------------------------
+def _any(_v) -> bool:
+    return True
+
+
+def _is(*vals):
+    return lambda v: any(v == x or (isinstance(x, float) and isinstance(v, (int, float)) and abs(v - x) < 1e-12)
+                         for x in vals)
+
+
+def _seq_is(*vals):
+    """value given as a list / tuple equal to one of ``vals`` (compared as float tuples)"""
+    def ok(v):
+        try:
+            t = tuple(float(x) for x in v)
+        except TypeError:
+            return False
+        return any(t == tuple(float(x) for x in w) for w in vals)
+    return ok
+
+
+def _keys_in(*allowed):
+    def ok(v):
+        ks = [v] if isinstance(v, str) else list(v)
+        return all(k in allowed for k in ks) and len(ks) > 0
+    return ok
+
+
+_IMG_LAB = _keys_in("image", "label")
+_IMG = _keys_in("image")
+_COMMON = {"allow_missing_keys": _is(False)}
+
+
+def _validate(t: "TransformSpec", what: str, table: Dict[str, Any], required=()) -> None:
+    table = dict(_COMMON, **table)
+    for k, v in t.kwargs.items():
+        if k not in table:
+            raise ValueError(f"'{what}': {t.target}({k}=...) -- this argument is not implemented by segmantic_amd's "
+                             f"on-device pipeline (accepted: {', '.join(sorted(table))})")
+        if not table[k](v):
+            raise ValueError(f"'{what}': {t.target}({k}={v!r}) differs from what segmantic_amd's on-device pipeline "
+                             f"does; it would silently train / predict with another value, so it is refused")
+    for k in required:
+        if k not in t.kwargs:
+            raise ValueError(f"'{what}': {t.target} needs an explicit '{k}' (its MONAI default differs from the "
+                             f"on-device pipeline)")
+
+
+def _spacing_modes(kw, what) -> bool:
+    """-> label_nearest.  ``mode`` of Spacingd: one mode for all keys or one per key (image, label)."""
+    keys = kw.get("keys", ["image", "label"])
+    keys = [keys] if isinstance(keys, str) else list(keys)
+    mode = kw.get("mode", "bilinear")
+    modes = [mode] * len(keys) if isinstance(mode, str) else list(mode)
+    if len(modes) != len(keys):
+        raise ValueError(f"'{what}': Spacingd mode {mode!r} does not match keys {keys!r}")
+    label_nearest = False
+    for k, m in zip(keys, modes):
+        m = str(m).lower()
+        if k == "image" and m != "bilinear":
+            raise ValueError(f"'{what}': Spacingd resamples the image with mode='bilinear' on the device, not {m!r}")
+        if k == "label":
+            if m not in ("bilinear", "nearest"):
+                raise ValueError(f"'{what}': Spacingd label mode must be 'bilinear' or 'nearest', not {m!r}")
+            label_nearest = m == "nearest"
+    return label_nearest
+
+
 def plan_preprocessing(comp) -> Optional[dict]:
     """Compose -> settings of ``PredictPipeline`` (load -> RAS -> normalise -> crop foreground ->
     float32 -> optional Spacing); ``None`` = use the default pipeline.  The stage ORDER is fixed on
-    the device, so a composition that orders the stages differently is refused."""
-    flat = _check(comp, PREPROCESSING, "preprocessing")
+    the device, so a composition that orders the stages differently is refused; so is any keyword
+    the device stages do not implement (see ``_validate``)."""
+    what = "preprocessing"
+    flat = _check(comp, PREPROCESSING, what)
     if flat is None:
         return None
     order = {n: i for i, n in enumerate(PREPROCESSING)}
@@ -158,47 +233,140 @@ def plan_preprocessing(comp) -> Optional[dict]:
     if [order[t.name] for t in seq] != sorted(order[t.name] for t in seq):
         raise ValueError("'preprocessing': the on-device pipeline runs LoadImage, EnsureChannelFirst, Orientation, "
                          "NormalizeIntensity, CropForeground, EnsureType, Spacing in this order")
-    plan = {"orientation": False, "normalize": False, "crop_foreground": False, "spacing": []}
+    plan = {"orientation": False, "normalize": False, "crop_foreground": False, "spacing": [],
+            "spacing_label_nearest": False}
     for t in seq:
         kw = t.kwargs
-        if t.name == "Orientation":
-            if str(kw.get("axcodes", "RAS")).upper() != "RAS":
-                raise ValueError("'preprocessing': Orientationd is implemented for axcodes='RAS'")
+        if t.name == "LoadImage":
+            _validate(t, what, {"keys": _IMG_LAB, "reader": _is(None, "ITKReader", "itkreader", "NibabelReader"),
+                                "image_only": _any, "ensure_channel_first": _any, "dtype": _any,
+                                "meta_keys": _any, "meta_key_postfix": _any, "overwriting": _any,
+                                "simple_keys": _any})
+        elif t.name == "EnsureChannelFirst":
+            _validate(t, what, {"keys": _IMG_LAB, "strict_check": _any, "channel_dim": _is(None, "no_channel", 0)})
+        elif t.name == "Orientation":
+            _validate(t, what, {"keys": _IMG_LAB, "axcodes": lambda v: str(v).upper() == "RAS",
+                                "as_closest_canonical": _is(False), "labels": _any})
             plan["orientation"] = True
         elif t.name == "NormalizeIntensity":
-            if kw.get("nonzero", False) or not kw.get("channel_wise", True) or kw.get("subtrahend") is not None \
-                    or kw.get("divisor") is not None:
-                raise ValueError("'preprocessing': NormalizeIntensityd is implemented for nonzero=False, "
-                                 "channel_wise=True without fixed subtrahend / divisor (the reference's default)")
+            _validate(t, what, {"keys": _IMG, "nonzero": _is(False), "channel_wise": _is(True),
+                                "subtrahend": _is(None), "divisor": _is(None), "dtype": _any},
+                      required=("channel_wise",))
             plan["normalize"] = True
         elif t.name == "CropForeground":
-            if kw.get("margin", 0) not in (0, [0, 0, 0]) or kw.get("k_divisible", 1) != 1:
-                raise ValueError("'preprocessing': CropForegroundd is implemented without margin / k_divisible")
+            _validate(t, what, {"keys": _IMG_LAB, "source_key": _is("label", "image"), "allow_smaller": _any,
+                                "margin": lambda v: v in (0, [0, 0, 0], (0, 0, 0), [0, 0], (0, 0)),
+                                "k_divisible": _is(1), "select_fn": _is(None), "channel_indices": _is(None),
+                                "mode": _any, "start_coord_key": _any, "end_coord_key": _any, "lazy": _is(False)},
+                      required=("source_key",))
             plan["crop_foreground"] = True
+        elif t.name == "EnsureType":
+            _validate(t, what, {"keys": _IMG_LAB, "dtype": _any, "device": _any, "data_type": _is("tensor"),
+                                "wrap_sequence": _any, "track_meta": _any})
         elif t.name == "Spacing":
+            _validate(t, what, {"keys": _IMG_LAB, "pixdim": _any, "mode": _any, "padding_mode": _is("border"),
+                                "diagonal": _is(False), "align_corners": _any, "dtype": _any,
+                                "scale_extent": _is(False), "recompute_affine": _is(False),
+                                "min_pixdim": _is(None), "max_pixdim": _is(None), "ensure_same_shape": _any,
+                                "lazy": _is(False)}, required=("pixdim",))
             plan["spacing"] = [float(v) for v in kw["pixdim"]]
+            plan["spacing_label_nearest"] = _spacing_modes(kw, what)
     return plan
 
 
+_SPATIAL_MODES = lambda v: all(str(m).lower() in ("nearest", "bilinear", "area", "trilinear")           # noqa: E731
+                               for m in ([v] if isinstance(v, str) else v))
+_INTENSITY = {
+    "RandAdjustContrast": {"keys": _IMG, "prob": _is(0.2), "gamma": _seq_is((0.5, 4.5)),
+                           "invert_image": _is(False), "retain_stats": _is(False)},
+    "RandHistogramShift": {"keys": _IMG, "prob": _is(0.2), "num_control_points": _is(10)},
+    "RandBiasField": {"keys": _IMG, "prob": _is(0.2), "degree": _is(3), "coeff_range": _seq_is((0.0, 0.1)),
+                      "dtype": _any},
+    "RandGibbsNoise": {"keys": _IMG, "prob": _is(0.2), "alpha": _seq_is((0.0, 1.0))},
+    "RandKSpaceSpikeNoise": {"keys": _IMG, "prob": _is(0.2), "intensity_range": _is(None),
+                             "channel_wise": _is(True)},
+}
+
+
 def plan_augmentation(comp) -> Optional[dict]:
-    """Compose -> {num_samples, flip_prob, augment_spatial, augment_intensity}; ``None`` = defaults."""
-    flat = _check(comp, AUGMENTATION, "augmentation")
+    """Compose -> {num_samples, flip_prob, flip_axes, augment_spatial, augment_intensity, spatial_size,
+    num_classes}; ``None`` = defaults.  The device sampler implements the reference's
+    ``default_augmentation`` (``monai_unet.py:178-219``) and nothing else: the spatial block is the
+    three RandRotated + RandZoomd with the reference's arguments or absent, the intensity block the
+    five transforms with the reference's arguments or absent, RandFlipd one entry per spatial axis
+    with one probability; partial blocks and other argument values are refused."""
+    what = "augmentation"
+    flat = _check(comp, AUGMENTATION, what)
     if flat is None:
         return None
     names = [t.name for t in flat]
     if "RandCropByLabelClasses" not in names:
         raise ValueError("'augmentation': the training sampler needs RandCropByLabelClassesd (patch extraction)")
-    plan = {"num_samples": 4, "flip_prob": 0.0, "augment_spatial": False, "augment_intensity": False,
-            "spatial_size": None}
+    plan = {"num_samples": 4, "flip_prob": 0.0, "flip_axes": [], "augment_spatial": False,
+            "augment_intensity": False, "spatial_size": None, "num_classes": None}
+    flips, rots, zooms, intens = [], [], [], {}
     for t in flat:
         kw = t.kwargs
-        if t.name == "RandCropByLabelClasses":
+        if t.name == "SpatialPad":
+            _validate(t, what, {"keys": _IMG_LAB, "spatial_size": _any, "method": _is("symmetric"),
+                                "mode": _is("constant"), "lazy": _is(False)})
+            plan["pad_size"] = kw.get("spatial_size")
+        elif t.name == "RandCropByLabelClasses":
+            _validate(t, what, {"keys": _IMG_LAB, "label_key": _is("label"), "spatial_size": _any,
+                                "num_samples": _any, "num_classes": _any, "ratios": _any,
+                                "image_key": _is(None), "image_threshold": _any, "indices_key": _is(None),
+                                "allow_smaller": _is(False), "warn": _any, "max_samples_per_class": _is(None),
+                                "lazy": _is(False)}, required=("ratios",))
+            r = [float(v) for v in kw["ratios"]]
+            if len(r) < 2 or r[0] != 0.0 or any(v != r[1] or v <= 0 for v in r[1:]):
+                raise ValueError("'augmentation': RandCropByLabelClassesd ratios must be [0, 1, 1, ...] (no background "
+                                 f"centres, all other classes alike) -- the sampler the device implements; got {kw['ratios']!r}")
+            if kw.get("num_classes") is not None and int(kw["num_classes"]) != len(r):
+                raise ValueError("'augmentation': RandCropByLabelClassesd num_classes does not match len(ratios)")
+            plan["num_classes"] = len(r)
             plan["num_samples"] = int(kw.get("num_samples", 1))
             plan["spatial_size"] = kw.get("spatial_size")
         elif t.name == "RandFlip":
-            plan["flip_prob"] = float(kw.get("prob", 0.1))
-        elif t.name in ("RandRotate", "RandZoom"):
-            plan["augment_spatial"] = True
-        elif t.name.startswith("Rand") and t.name not in ("RandFlip",):
-            plan["augment_intensity"] = True
+            _validate(t, what, {"keys": _IMG_LAB, "prob": _any, "spatial_axis": lambda v: v in (0, 1, 2),
+                                "lazy": _is(False)}, required=("spatial_axis",))
+            flips.append((int(kw["spatial_axis"]), float(kw.get("prob", 0.1))))
+        elif t.name == "RandRotate":
+            _validate(t, what, {"keys": _IMG_LAB, "prob": _is(0.2), "range_x": _is(0.0, 0.4), "range_y": _is(0.0, 0.4),
+                                "range_z": _is(0.0, 0.4), "keep_size": _is(True), "mode": _SPATIAL_MODES,
+                                "padding_mode": _is("border"), "align_corners": _is(False), "dtype": _any,
+                                "lazy": _is(False)}, required=("prob",))
+            rots.append(tuple(ax for ax in "xyz" if float(kw.get(f"range_{ax}", 0.0)) != 0.0))
+        elif t.name == "RandZoom":
+            _validate(t, what, {"keys": _IMG_LAB, "prob": _is(0.2), "min_zoom": _is(0.8), "max_zoom": _is(1.3),
+                                "mode": _SPATIAL_MODES, "padding_mode": _is("edge"), "align_corners": _is(None),
+                                "keep_size": _is(True), "dtype": _any, "lazy": _is(False)},
+                      required=("prob", "min_zoom", "max_zoom"))
+            zooms.append(t)
+        elif t.name in _INTENSITY:
+            _validate(t, what, _INTENSITY[t.name], required=("prob",))
+            if t.name in intens:
+                raise ValueError(f"'augmentation': {t.target} appears twice")
+            intens[t.name] = t
+        elif t.name == "EnsureType":
+            _validate(t, what, {"keys": _IMG_LAB, "dtype": _any, "device": _any, "data_type": _is("tensor"),
+                                "wrap_sequence": _any, "track_meta": _any})
+        # DataStats: prints only
+    if flips:
+        axes = sorted(a for a, _ in flips)
+        probs = {p for _, p in flips}
+        if axes not in ([0, 1], [0, 1, 2]) or len(probs) != 1:
+            raise ValueError("'augmentation': RandFlipd must be configured once per spatial axis (spatial_axis 0, 1[, 2]) "
+                             f"with one probability -- the device flips every axis independently; got {flips!r}")
+        plan["flip_prob"], plan["flip_axes"] = probs.pop(), axes
+    if rots or zooms:
+        if sorted(rots) != [("x",), ("y",), ("z",)] or len(zooms) != 1:
+            raise ValueError("'augmentation': the device implements the reference's spatial block as a whole -- "
+                             "RandRotated(prob=0.2, range_z=0.4), RandRotated(range_x=0.4), RandRotated(range_y=0.4) and "
+                             "RandZoomd(prob=0.2, min_zoom=0.8, max_zoom=1.3) -- or none of it")
+        plan["augment_spatial"] = True
+    if intens:
+        if set(intens) != set(_INTENSITY):
+            raise ValueError("'augmentation': the device implements the reference's intensity block as a whole ("
+                             + ", ".join(n + "d" for n in _INTENSITY) + f") or none of it; got only {sorted(intens)}")
+        plan["augment_intensity"] = True
     return plan

@@ -213,3 +213,67 @@ def test_gradient_buckets_through_rccl_with_one_rank(tmp_path):
     mp.spawn(_rccl_worker, args=(1, port, str(tmp_path), True), nprocs=1, join=True)
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), False), nprocs=1, join=True)
     assert torch.equal(torch.load(tmp_path / "rccl_1.pt"), torch.load(tmp_path / "rccl_0.pt"))
+
+
+def _fresh_env():
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PYTHONPATH=str(root), SEGMI_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return root, env, sys.executable
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` un-wrapped: the parent -- a fresh process that has
+    not touched the GPU -- starts two ranks (both on this box's one GPU, gloo transport), rank 0 prints
+    the JSON line, the launcher's exit code comes back."""
+    import json
+    import subprocess
+    root, env, py = _fresh_env()
+    p = subprocess.run([py, str(root / "bench.py"), "--gpus", "2", "--workload", "train", "--steps", "2",
+                        "--warmup", "1", "--size", "32", "--batch", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    gx = out["config"]["gradient_exchange"]
+    assert gx["backend"] == "gloo" and gx["bytes_per_step"] > 0 and gx["exposed_allreduce_ms_per_step_rank0"] >= 0
+
+
+def test_cli_train_with_two_gpu_ids_starts_its_own_ranks(tmp_path):
+    """`segmantic-unet train-config` with `gpu_ids: [0, 0]` from a plain process: train() hands the call
+    to two ranks it starts itself (reference: pl.Trainer(devices=len(gpu_ids)), monai_unet.py:529-538)."""
+    import json
+    import subprocess
+
+    import numpy as np
+    from oracle.unet_ref import synthetic_batch
+    from segmantic_amd.data.nifti import write_nifti
+    root, env, py = _fresh_env()
+    data = tmp_path / "data"
+    (data / "image").mkdir(parents=True)
+    (data / "label").mkdir()
+    A = np.diag([1.0, 1.0, 1.0, 1.0])
+    for i in range(4):
+        img, lab = synthetic_batch(1, 24, 3, seed=80 + i)
+        write_nifti(data / "image" / f"c{i}.nii.gz", (img[0, 0].numpy() * 100 + 300).astype(np.float32).transpose(2, 1, 0), A)
+        write_nifti(data / "label" / f"c{i}.nii.gz", lab[0, 0].numpy().astype(np.uint8).transpose(2, 1, 0), A)
+    dl = {"labels": {"1": "a", "2": "b"},
+          "training": [{"image": f"image/c{i}.nii.gz", "label": f"label/c{i}.nii.gz"} for i in range(3)],
+          "validation": [{"image": "image/c3.nii.gz", "label": "label/c3.nii.gz"}], "test": []}
+    (data / "dataset.json").write_text(json.dumps(dl))
+    out = tmp_path / "results"
+    cfg = {"datalist": str(data / "dataset.json"), "output_dir": str(out), "spatial_size": [16, 16, 16],
+           "channels": list(CH), "strides": list(ST), "max_epochs": 1, "num_samples": 2, "gpu_ids": [0, 0]}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    p = subprocess.run([py, "-m", "segmantic_amd.commands.monai_unet_cli", "train-config", "-c",
+                        str(tmp_path / "cfg.json")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "[rank 0/2]" in p.stdout and "[rank 1/2]" in p.stdout
+    assert len(list(out.glob("epoch=0-val_loss=*-val_dice=*.ckpt"))) == 1      # rank 0 only
+    assert not list(out.glob("ranks_*.json"))                                  # the hand-over file is gone

@@ -797,3 +797,61 @@ def test_train_config_with_bundle_dictionaries_adabelief_and_mixed_image_formats
     (tmp_path / "bad.yml").write_text(yaml.safe_dump(cfg))
     res = runner.invoke(app, ["train-config", "-c", str(tmp_path / "bad.yml")])
     assert res.exit_code != 0 and "RandGaussianNoised" in str(res.exception)
+
+
+def _hip_trajectory(cfg, mixed_precision):
+    """the protocol of tests/golden/make_convergence_golden.py on the HIP path"""
+    K, S, B = cfg["labels"], cfg["patch"], cfg["batch"]
+    _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
+    net.mixed_precision = mixed_precision
+    net.optimizer = dict(Net.optimizer, lr=cfg["lr"])
+    net.train()
+    val = [synthetic_batch(1, S, K, seed=900 + i) for i in range(cfg["val_volumes"])]
+    out = {"train_loss": [], "val_dice": [], "val_loss": []}
+    for step in range(cfg["steps"]):
+        img, lab = synthetic_batch(B, S, K, seed=100 + step)
+        res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+        out["train_loss"].append(float(res["loss"].cpu()))
+        if (step + 1) % cfg["validate_every"] == 0:
+            for img_v, lab_v in val:                           # reference validation_step, :350-363
+                net.validation_step({"image": img_v.to(DEV), "label": lab_v.to(DEV)})
+            losses = [float(o["val_loss"].sum().item()) for o in net.validation_step_outputs]
+            out["val_loss"].append(sum(losses) / len(losses))
+            out["val_dice"].append(float(net.dice_metric.aggregate().item()))
+            net.dice_metric.reset()
+            net.validation_step_outputs.clear()
+            net.train()
+    return out
+
+
+def test_convergence_matches_cpu_reference(golden_dir, record_property):
+    """north_star's last gate: "Dice within 1e-4 of the CPU reference on synthetic data" (reference
+    path monai_unet.py:339-397).  30 training steps of BASELINE config 1 (32^3, 3 labels, batch 8, fp32,
+    Adam) from the same weights on the same batches, validation (sliding window roi 160, argmax,
+    DiceMetric) every 10 steps; the CPU oracle's trajectory is committed
+    (tests/golden/convergence_c1.json, two runs with different thread counts: the validation Dice is a
+    discrete function of near-tied logits, and the oracle's own spread reaches 1.1e-4 at step 30).
+    f32 path: every validation Dice within 1e-4 of the nearest oracle run, every training loss within
+    1e-4 relative.  bf16 path: deviation recorded, loosely bounded."""
+    g = json.loads((golden_dir / "convergence_c1.json").read_text())
+    cfg, runs = g["config"], g["runs"]
+    hip = _hip_trajectory(cfg, mixed_precision=False)
+    dd = [min(abs(h - r["val_dice"][i]) for r in runs) for i, h in enumerate(hip["val_dice"])]
+    dl = [min(abs(h - r["val_loss"][i]) for r in runs) for i, h in enumerate(hip["val_loss"])]
+    dt = max(min(abs(h - r["train_loss"][i]) / r["train_loss"][i] for r in runs)
+             for i, h in enumerate(hip["train_loss"]))
+    print(f"\nconvergence f32: |val_dice - oracle| = {dd}, |val_loss - oracle| = {dl}, train-loss rel. {dt:.2e}; "
+          f"oracle self-spread {g['oracle_self_spread']['val_dice']}")
+    record_property("f32_val_dice_dev", dd)
+    assert len(hip["val_dice"]) == len(runs[0]["val_dice"]) == 3
+    assert max(dd) <= 1e-4, (hip["val_dice"], [r["val_dice"] for r in runs])
+    assert max(dl) <= 1e-4, (hip["val_loss"], [r["val_loss"] for r in runs])
+    assert dt <= 1e-4
+    assert hip["train_loss"][-1] < hip["train_loss"][0] - 0.02           # it does train
+    # bf16 (the benchmarked precision): reported, with a loose sanity bound
+    hb = _hip_trajectory(cfg, mixed_precision=True)
+    bd = [min(abs(h - r["val_dice"][i]) for r in runs) for i, h in enumerate(hb["val_dice"])]
+    bt = max(abs(h - runs[0]["train_loss"][i]) / runs[0]["train_loss"][i] for i, h in enumerate(hb["train_loss"]))
+    print(f"convergence bf16: |val_dice - oracle| = {bd}, train-loss rel. {bt:.2e}")
+    record_property("bf16_val_dice_dev", bd)
+    assert max(bd) < 5e-2 and bt < 2e-2

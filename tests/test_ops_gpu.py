@@ -998,6 +998,36 @@ def test_ensemble_kernels_match_monai_semantics():
     assert torch.equal(lo.cpu(), ref)
 
 
+def test_ensemble_select_matches_the_reference_test_vector(golden_dir):
+    """The reference's own SelectBestEnsembled vector (tests/seg/test_transforms.py:9-43, committed as
+    tests/golden/reference_select_best.json): label form through ops.ensemble_select, one-hot form
+    through the product's argmax -> select -> one-hot chain (ensemble_creator, monai_unet.py)."""
+    import json
+
+    from oracle.ensemble_ref import ref_select_best
+    from segmantic_amd.seg.monai_unet import _argmax_labels, _one_hot_logits
+    g = json.loads((golden_dir / "reference_select_best.json").read_text())
+    lmd = {int(t): int(m) for t, m in g["label_model_dict"]}
+    want = torch.tensor(g["expected"], dtype=torch.int32)
+    labs = [torch.tensor(p, dtype=torch.int32).to(DEV) for p in g["preds"]]
+    out = torch.full((3,), -1, dtype=torch.int32, device=DEV)
+    ops.ensemble_select(labs, lmd, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
+    # one-hot form: [K, 3, 1, 1] score maps per model -> arg-max labels -> select -> one-hot
+    k = g["num_classes"]
+    onehots = [torch.nn.functional.one_hot(torch.tensor(p), k).T.reshape(1, k, 3, 1, 1).float().to(DEV)
+               for p in g["preds"]]
+    labs2 = [_argmax_labels(o)[0, 0].contiguous() for o in onehots]
+    out2 = torch.empty_like(labs2[0])
+    ops.ensemble_select(labs2, lmd, out2)
+    got = _one_hot_logits(out2, k)
+    torch.cuda.synchronize()
+    ref = ref_select_best([o[0].cpu() for o in onehots], lmd)
+    assert torch.equal(got.cpu(), ref)
+    assert torch.equal(got.cpu().argmax(0).reshape(-1).int(), want)
+
+
 def test_confusion_matrix_metric_and_empty_dice_aggregate_match_monai_rule():
     """reference monai_unet.py:645-646, 705-725: ConfusionMatrixMetric(sensitivity, specificity,
     precision, accuracy) -- tp/fp/tn/fn averaged over (volume, class) first, then the ratios."""

@@ -176,3 +176,23 @@ def test_sliding_window_goldens(gold):
         assert np.array_equal(np.bincount(cnt.reshape(-1).numpy().astype(np.int64)), gold[tag + "_count_hist"])
         np.testing.assert_allclose(o[0, :, 10:14, 10:14, 10:14].numpy(), gold[tag + "_out_block"], atol=1e-5)
     assert int(gold["sw512_nwin"]) == 343 and int(gold["sw512_nwin_ov25"]) == 125
+
+
+# ------------------------------------------------------------------ pinned by the reference's own vector
+def test_select_best_matches_the_reference_test_vector(golden_dir):
+    """/root/reference/tests/seg/test_transforms.py:9-43: preds [1,1,1] / [2,0,2] / [2,1,0], dict
+    {1: 0, 2: 1, 0: 2} -> [2,1,0]; then the same through one_hot(num_classes=3, dim=0)."""
+    import json
+
+    from oracle.ensemble_ref import ref_select_best
+    g = json.loads((golden_dir / "reference_select_best.json").read_text())
+    shape = tuple(g["shape"])
+    preds = [torch.tensor(p, dtype=torch.float32).reshape(shape) for p in g["preds"]]
+    lmd = {int(t): int(m) for t, m in g["label_model_dict"]}
+    assert list(lmd.items()) == [(1, 0), (2, 1), (0, 2)]                    # insertion order matters
+    want = torch.tensor(g["expected"], dtype=torch.float32).reshape(shape)
+    assert torch.equal(ref_select_best(preds, lmd), want)
+    k = g["num_classes"]
+    oh = lambda t: F.one_hot(t.long()[0], k).movedim(-1, 0).float()         # monai one_hot(dim=0) of [1, ...]
+    got = ref_select_best([oh(p) for p in preds], lmd)
+    assert got.shape == (k,) + shape[1:] and torch.equal(got, oh(want))

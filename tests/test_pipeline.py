@@ -169,3 +169,37 @@ def test_predict_chain_round_trip_reproduces_label(tmp_path):
     onehot = torch.zeros((K,) + tuple(pl.shape), device="cuda:0").scatter_(0, pl[None], 1.0)
     got = pipe.invert_and_discretize(onehot, item).cpu().numpy()
     assert np.array_equal(got, lab.transpose(2, 1, 0))
+
+
+@pytest.mark.gpu
+def test_spacing_with_a_nearest_label_mode_keeps_integer_labels(tmp_path):
+    """Spacingd(mode=[bilinear, nearest]) from a bundle config (utils/bundle.py plans
+    ``spacing_label_nearest``): the label volume is resampled with MONAI's nearest rule (torch
+    grid_sample: nearbyint, i.e. half to even -- a 2x spacing change hits x.5 on every other voxel),
+    the image bilinearly as before."""
+    from segmantic_amd.data.nifti import read_nifti, write_nifti
+    A = AFFINES[1]
+    K = 5
+    lab = _blob_labels((18, 22, 26), K, 4)
+    img = (np.random.RandomState(3).rand(18, 22, 26) * 50 + 10 * lab).astype(np.float32)
+    write_nifti(tmp_path / "img.nii.gz", img, A)
+    write_nifti(tmp_path / "lab.nii.gz", lab, A)
+    _, A_file = read_nifti(tmp_path / "img.nii.gz")
+    sp_in = np.sqrt((A_file[:3, :3] ** 2).sum(0))
+    for factor in (2.0, 0.5, 1.3):
+        spacing = tuple(float(v) * factor for v in sp_in)
+        pipe = P.PredictPipeline(device="cuda:0", spacing=spacing, with_label=True, label_nearest=True)
+        item = pipe.load(tmp_path / "img.nii.gz", tmp_path / "lab.nii.gz")
+        got = item["label"].cpu().numpy()
+        assert np.array_equal(got, np.round(got)) and set(np.unique(got)) <= set(range(K))
+        # oracle: same chain, label through the nearest resampler
+        vol = np.ascontiguousarray(img.transpose(2, 1, 0))[None]
+        labv = np.ascontiguousarray(lab.transpose(2, 1, 0))[None].astype(np.float32)
+        rec = R.ref_preprocess(vol, A_file, (), labv, A_file)          # up to the crop
+        want, _ = R.ref_spacing(rec["label"], rec["affine_crop"], spacing, nearest=True)
+        assert got.shape == want.shape and np.array_equal(got, want), factor
+        # the bilinear default of the reference still interpolates the label
+        soft = P.PredictPipeline(device="cuda:0", spacing=spacing, with_label=True).load(
+            tmp_path / "img.nii.gz", tmp_path / "lab.nii.gz")["label"].cpu().numpy()
+        if factor != 2.0:          # (a 2x coarser grid that starts on a voxel samples voxels exactly)
+            assert not np.array_equal(soft, np.round(soft))
