@@ -779,8 +779,15 @@ def test_train_config_with_bundle_dictionaries_adabelief_and_mixed_image_formats
                {"_target_": "RandCropByLabelClassesd", "keys": keys, "label_key": "@label_key",
                 "spatial_size": [16, 16, 16], "num_classes": 3, "num_samples": 3, "ratios": [0, 1, 1]},
                {"_target_": "RandFlipd", "keys": keys, "prob": 0.5, "spatial_axis": 0}]}}
-    (tmp_path / "cfg.yml").write_text(yaml.safe_dump(cfg))
     runner = CliRunner()
+    # a flip configured for ONE axis cannot be expressed by the device sampler (it flips every axis
+    # independently with one probability): refused by name instead of silently flipping all three
+    (tmp_path / "cfg.yml").write_text(yaml.safe_dump(cfg))
+    res = runner.invoke(app, ["train-config", "-c", str(tmp_path / "cfg.yml")])
+    assert res.exit_code != 0 and "RandFlipd" in str(res.exception)
+    cfg["augmentation"]["transforms"][2:] = [{"_target_": "RandFlipd", "keys": keys, "prob": 0.5, "spatial_axis": a}
+                                             for a in range(3)]
+    (tmp_path / "cfg.yml").write_text(yaml.safe_dump(cfg))
     res = runner.invoke(app, ["train-config", "-c", str(tmp_path / "cfg.yml")])
     assert res.exit_code == 0, (res.output, res.exception)
     ckpts = sorted((tmp_path / "results").glob("epoch=*-val_loss=*-val_dice=*.ckpt"))
