@@ -95,6 +95,32 @@ typedef struct segmi_in_affine {
   const float* shift;
   const float* prelu_alpha;
 } segmi_in_affine;
+/* Finalisation of a BatchNorm reduction carried out BY THE LAUNCH THAT PRODUCES THE PARTIAL ROWS: the
+ * workgroup that finishes last folds the rows in a fixed order (f64) and writes the per-channel
+ * results, so that no separate segmi_bn_finalize / segmi_bn_act_bwd_finalize launch sits on the
+ * dependent chain of the stream (csrc/fin_tail.h; ~40 launches per training step).  Deterministic:
+ * the fold order depends on the table shape only.  Same argument meaning as the separate calls.
+ * Replaces the statistics half of torch.nn.BatchNorm3d forward / backward under monai ADN,
+ * monai_unet.py:114-124, 345. */
+typedef struct segmi_bn_fin {       /* = the arguments of segmi_bn_finalize */
+  double count;                     /* voxels per channel (N*D*H*W of the conv output) */
+  const float* gamma;               /* nullable = 1 */
+  const float* beta;                /* nullable = 0 */
+  float* running_mean;              /* nullable */
+  float* running_var;               /* nullable */
+  float momentum, eps;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+} segmi_bn_fin;
+typedef struct segmi_bn_bwd_fin {   /* = the arguments of segmi_bn_act_bwd_finalize */
+  double count;
+  float* dgamma;                    /* nullable */
+  float* dbeta;                     /* nullable */
+  float* dalpha;                    /* nullable */
+  float* coef;                      /* f32[2][c] for segmi_bn_act_bwd_apply */
+} segmi_bn_bwd_fin;
 /* Optional epilogue of an INPUT-GRADIENT convolution (segmi_conv3d_fwd with a kind-1 pack) whose
  * output `out` is the gradient g flowing into a training-mode BatchNorm + PReLU: with x = that
  * layer's forward input (the raw output of its producer conv, same extents as `out`) the kernel
@@ -113,6 +139,7 @@ typedef struct segmi_bn_bwd_sums {
   const float* beta;         /* nullable = 0 */
   const float* prelu_alpha;  /* nullable = no activation */
   float* partials;
+  const segmi_bn_bwd_fin* fin;   /* nullable: also finalise in this launch (then no segmi_bn_act_bwd_finalize) */
 } segmi_bn_bwd_sums;
 int segmi_conv3d_bn_bwd_sums_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                                 int stride);
@@ -126,7 +153,8 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
                      float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
-                     const segmi_bn_bwd_sums* bn_bwd /* nullable */, void* stream);
+                     const segmi_bn_bwd_sums* bn_bwd /* nullable */,
+                     const segmi_bn_fin* stats_fin /* nullable; needs stats_partials */, void* stream);
 /* Inference, full-resolution decoder of monai UNet as ONE launch (csrc/dectop.hip):
  *   h = PReLU(ConvTranspose3d(k3, s2, p1, op1; 32 -> 16)(in) with BatchNorm folded), out = Conv3d(k3; 16 -> 16)(h) + bias + h
  * i.e. `up` layer "model.2.0" followed by the conv-only ResidualUnit "model.2.1" (monai_unet.py:114-124), whose
@@ -161,6 +189,7 @@ int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* 
 int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
                           const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
                           const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,
+                          const segmi_bn_fin* stats_fin_a /* nullable; needs stats_partials_a */,
                           void* stream);
 
 /* ConvTranspose3d k3 s2 p1 (output extent 2*in or 2*in-1 per dim, taken from `out`),
@@ -169,7 +198,8 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
 int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* out);
 int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
                       const float* w_src, const float* bias, const float* prelu_alpha,
-                      const segmi_act* residual, float* stats_partials, void* stream);
+                      const segmi_act* residual, float* stats_partials,
+                      const segmi_bn_fin* stats_fin /* nullable; needs stats_partials */, void* stream);
 
 /* Weight gradient of a Conv3d (k, stride as forward): dw[co][ci][tap] (torch layout, f32) and
  * db[co] (nullable) from x (forward input) and dy (grad of the conv output).  Two-stage
@@ -214,7 +244,8 @@ int segmi_bn_act_bwd_rows(const segmi_act* x);
 int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
                             const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* prelu_alpha, float* red_partials,
-                            float dropout_p, uint32_t dropout_seed, void* stream);
+                            float dropout_p, uint32_t dropout_seed,
+                            const segmi_bn_bwd_fin* fin /* nullable: finalise in this launch */, void* stream);
 int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double count,
                               const float* gamma, const float* invstd, float* dgamma,
                               float* dbeta, float* dalpha, float* coef, void* stream);

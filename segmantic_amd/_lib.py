@@ -43,11 +43,28 @@ class InAffine(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("prelu_alpha", C.c_void_p)]
 
 
+class BnFin(C.Structure):
+    """``segmi_bn_fin``: BatchNorm statistics finalised by the launch that produces the partial rows."""
+
+    _fields_ = [("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
+                ("eps", C.c_float), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p),
+                ("shift", C.c_void_p)]
+
+
+class BnBwdFin(C.Structure):
+    """``segmi_bn_bwd_fin``: BatchNorm-backward sums finalised by the launch that produces them."""
+
+    _fields_ = [("count", C.c_double), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dalpha", C.c_void_p),
+                ("coef", C.c_void_p)]
+
+
 class BnBwdSums(C.Structure):
     """``segmi_bn_bwd_sums``: BatchNorm-backward reduction fused into an input-gradient conv's epilogue."""
 
     _fields_ = [("x", C.POINTER(Act)), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
-                ("beta", C.c_void_p), ("prelu_alpha", C.c_void_p), ("partials", C.c_void_p)]
+                ("beta", C.c_void_p), ("prelu_alpha", C.c_void_p), ("partials", C.c_void_p),
+                ("fin", C.POINTER(BnBwdFin))]
 
 
 _P = C.c_void_p
@@ -70,14 +87,14 @@ SIGNATURES = {
     "segmi_conv3d_split_act_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_fwd_split_act": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _i, _i, _P]),
     "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, C.POINTER(InAffine),
-                              C.POINTER(BnBwdSums), _P]),
+                              C.POINTER(BnBwdSums), C.POINTER(BnFin), _P]),
     "segmi_conv3d_bn_bwd_sums_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_dectop_ok": (_i, [_i, _AP, _AP]),
     "segmi_dectop_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P]),
     "segmi_conv3d_pair_ok": (_i, [_i, _AP, _AP, _AP]),
-    "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, _P]),
+    "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, C.POINTER(BnFin), _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),
-    "segmi_convT3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P]),
+    "segmi_convT3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, C.POINTER(BnFin), _P]),
     "segmi_conv3d_wgrad_workspace": (_i64, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_wgrad": (_i, [_i, _AP, _AP, _P, _P, _i, _i, _P, C.POINTER(InAffine), _P]),
     "segmi_bias_grad": (_i, [_i, _AP, _P, _P, _P]),
@@ -87,7 +104,8 @@ SIGNATURES = {
     "segmi_bn_eval_affine": (_i, [_i, _P, _P, _P, _P, _f, _P, _P, _P]),
     "segmi_bn_act_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _AP, _f, C.c_uint32, _P]),
     "segmi_bn_act_bwd_rows": (_i, [_AP]),
-    "segmi_bn_act_bwd_reduce": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
+    "segmi_bn_act_bwd_reduce": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32,
+                                     C.POINTER(BnBwdFin), _P]),
     "segmi_bn_act_bwd_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _P, _P, _P]),
     "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
     "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),

@@ -15,11 +15,17 @@ int convt_mfma_bf16(const ConvTParams& p, hipStream_t st);
 int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
 int bn_stats_rows_for(const segmi_act* x);
 int stats_reserve_rows();
+// the separate finalisation launch with a segmi_bn_fin's arguments (generic / direct paths)
+static inline int bn_finalize_with(const float* partials, int rows, int c, const segmi_bn_fin* f, hipStream_t st) {
+  return segmi_bn_finalize(partials, rows, c, f->count, f->gamma, f->beta, f->running_mean, f->running_var,
+                           f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift, st);
+}
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
                    const float* bias, const float* alpha, const segmi_act* res, float* stats,
                    int stride, hipStream_t st, const segmi_act* out2 = nullptr,
-                   const float* w2 = nullptr, const float* bias2 = nullptr);
+                   const float* w2 = nullptr, const float* bias2 = nullptr,
+                   const segmi_bn_fin* fin = nullptr);
 int conv_small_fwd_rows(const segmi_act* out);
 
 struct DirectParams {
@@ -163,7 +169,9 @@ int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
 int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
                           const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
                           const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,
-                          void* stream) {
+                          const segmi_bn_fin* stats_fin_a, void* stream) {
+  SEGMI_CHECK_ARG(!stats_fin_a || (stats_partials_a && bn_fin_ok(stats_fin_a)),
+                  "conv3d_fwd_pair: stats_fin_a needs stats_partials_a and its output pointers");
   SEGMI_CHECK_ARG(segmi_conv3d_pair_ok(dtype, in, out_a, out_b),
                   "conv3d_fwd_pair: not a small-Cin k3 pair (ask segmi_conv3d_pair_ok first)");
   SEGMI_CHECK_ARG(w_a && w_b && (stride == 1 || stride == 2), "conv3d_fwd_pair: bad arguments");
@@ -173,7 +181,7 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
   SEGMI_CHECK_ARG(!(stats_partials_a && prelu_alpha_a),
                   "conv3d_fwd_pair: fused statistics are taken before PReLU");
   return conv_small_fwd(dtype, in, out_a, w_a, bias_a, prelu_alpha_a, nullptr, stats_partials_a,
-                        stride, (hipStream_t)stream, out_b, w_b, bias_b);
+                        stride, (hipStream_t)stream, out_b, w_b, bias_b, stats_fin_a);
 }
 
 int segmi_conv3d_split_act_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
@@ -250,7 +258,11 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
                      const float* w_src, int w_kind, const float* bias,
                      const float* prelu_alpha, const segmi_act* residual,
                      float* stats_partials, int ksize, int stride, const segmi_in_affine* in_tf,
-                     const segmi_bn_bwd_sums* bn_bwd, void* stream) {
+                     const segmi_bn_bwd_sums* bn_bwd, const segmi_bn_fin* stats_fin, void* stream) {
+  SEGMI_CHECK_ARG(!stats_fin || (stats_partials && bn_fin_ok(stats_fin)),
+                  "conv3d: stats_fin needs stats_partials and its output pointers");
+  if (bn_bwd && bn_bwd->fin)
+    SEGMI_CHECK_ARG(bn_bwd->fin->count > 0 && bn_bwd->fin->coef, "conv3d: bn_bwd->fin needs count and coef");
   if (bn_bwd)
     SEGMI_CHECK_ARG(bn_bwd->x && act_ok(bn_bwd->x) && bn_bwd->mean && bn_bwd->invstd && bn_bwd->partials &&
                         segmi_conv3d_bn_bwd_sums_ok(dtype, in, out, ksize, stride) && !prelu_alpha &&
@@ -300,7 +312,13 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
       p.bgamma = bn_bwd->gamma; p.bbeta = bn_bwd->beta; p.balpha = bn_bwd->prelu_alpha;
       p.bpart = bn_bwd->partials;
       SEGMI_CHECK_ARG((int64_t)p.Ho * p.Wo * p.ldbx < (1ll << 31), "conv3d: plane too large for 32-bit offsets");
+      if (bn_bwd->fin) {
+        p.fin_on = 1;
+        p.bbfin = BnBwdFin{out->c, bn_bwd->fin->count, bn_bwd->fin->dgamma, bn_bwd->fin->dbeta,
+                           bn_bwd->fin->dalpha, bn_bwd->fin->coef};
+      }
     }
+    if (stats_fin) { p.fin_on = 1; p.bfin = bn_fin_from(stats_fin, out->c); }
     return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st)
                               : conv_mfma_bf16(p, ksize, stride, st);
   }
@@ -313,7 +331,7 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
     SEGMI_CHECK_ARG(!stats_partials || (!prelu_alpha && !residual),
                     "conv3d: fused statistics are taken before PReLU/residual");
     return conv_small_fwd(dtype, in, out, w_src, bias, prelu_alpha, residual, stats_partials, stride,
-                          st);
+                          st, nullptr, nullptr, nullptr, stats_fin);
   }
   DirectParams p{};
   p.in = in->data; p.out = out->data; p.w = w_src; p.bias = bias; p.alpha = prelu_alpha;
@@ -329,7 +347,10 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
   if (stats_partials) {
     SEGMI_CHECK_ARG(!prelu_alpha && !residual,
                     "conv3d: fused statistics are taken before PReLU/residual");
-    return bn_stats_launch(dtype, out, stats_partials, st);
+    const int rc = bn_stats_launch(dtype, out, stats_partials, st);
+    if (rc != SEGMI_OK || !stats_fin) return rc;
+    return bn_finalize_with(stats_partials, segmi_conv3d_stats_rows(dtype, in, out, ksize, stride), out->c,
+                            stats_fin, st);       // generic path: a separate (small) launch
   }
   return SEGMI_OK;
 }
@@ -342,7 +363,10 @@ int segmi_convT3d_stats_rows(int dtype, const segmi_act* in, const segmi_act* ou
 
 int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
                       const float* w_src, const float* bias, const float* prelu_alpha,
-                      const segmi_act* residual, float* stats_partials, void* stream) {
+                      const segmi_act* residual, float* stats_partials, const segmi_bn_fin* stats_fin,
+                      void* stream) {
+  SEGMI_CHECK_ARG(!stats_fin || (stats_partials && bn_fin_ok(stats_fin)),
+                  "convT3d: stats_fin needs stats_partials and its output pointers");
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "convT3d: bad dtype %d", dtype);
   SEGMI_CHECK_ARG(act_ok(in) && act_ok(out), "convT3d: bad activation view");
   SEGMI_CHECK_ARG(in->n == out->n, "convT3d: batch mismatch");
@@ -373,6 +397,7 @@ int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, cons
     p.ldr = residual ? residual->ld : 0;
     p.nchunks = in->c / pick_ck(dtype, in->c);
     p.ntiles_total = out->c / 16;
+    if (stats_fin) { p.fin_on = 1; p.bfin = bn_fin_from(stats_fin, out->c); }
     return dtype == SEGMI_F32 ? convt_mfma_f32(p, st) : convt_mfma_bf16(p, st);
   }
   SEGMI_CHECK_ARG(w_src, "convT3d: direct path (channels not multiples of 16) needs w_src");
@@ -390,7 +415,9 @@ int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, cons
   if (stats_partials) {
     SEGMI_CHECK_ARG(!prelu_alpha && !residual,
                     "convT3d: fused statistics are taken before PReLU/residual");
-    return bn_stats_launch(dtype, out, stats_partials, st);
+    const int rc = bn_stats_launch(dtype, out, stats_partials, st);
+    if (rc != SEGMI_OK || !stats_fin) return rc;
+    return bn_finalize_with(stats_partials, segmi_convT3d_stats_rows(dtype, in, out), out->c, stats_fin, st);
   }
   return SEGMI_OK;
 }

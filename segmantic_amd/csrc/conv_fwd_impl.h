@@ -10,6 +10,7 @@
 // per lane, a fully coalesced NDHWC row per 4 lanes.
 #pragma once
 #include "common.h"
+#include "fin_tail.h"
 
 namespace segmi {
 
@@ -41,6 +42,13 @@ struct ConvParams {
   int ldbx;
   const float* bmean; const float* binvstd; const float* bgamma; const float* bbeta; const float* balpha;
   float* bpart;
+  // finalisation inside this launch (fin_tail.h): the workgroup that finishes last folds `stats`
+  // (BnFin: segmi_bn_fin) or `bpart` (BnBwdFin: segmi_bn_bwd_sums.fin); fin_on is set by the C entry
+  // point, ft by the launcher (which knows the grid)
+  int fin_on;
+  FinTail ft;
+  BnFin bfin;
+  BnBwdFin bbfin;
   int xcd;   // ring2: 1 = XCD-aware blockIdx -> column map (grid.x % 8 == 0)
   int dbg;   // diagnostics only (SEGMI_RING2_DBG): 1 = no staging loads, 2 = no stores, 4 = no MFMA loop
 };
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
       p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
   }
 }
 
@@ -302,7 +311,9 @@ static int launch_conv_cfg(ConvParams p, hipStream_t st) {
   const int64_t nb = (int64_t)p.N * p.tz * p.ty * p.tx;
   SEGMI_CHECK_ARG(nb < (1ll << 31), "conv3d: too many tiles");
   dim3 grid((unsigned)nb, (unsigned)(p.Cout / (16 * NT)));
-  constexpr int lds = G::LDS_BYTES > 4 * 2 * NT * 16 * 4 ? G::LDS_BYTES : 4 * 2 * NT * 16 * 4;
+  constexpr int lds0 = G::LDS_BYTES > 4 * 2 * NT * 16 * 4 ? G::LDS_BYTES : 4 * 2 * NT * 16 * 4;
+  p.fin_on = p.fin_on && p.stats;
+  const int lds = (int)fin_tail_arm(p, grid, 256, 2 * p.Cout, lds0);
   auto kern = conv_fwd_mfma_kernel<T, CK, KS, S, NT, TD, TH, TW>;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {

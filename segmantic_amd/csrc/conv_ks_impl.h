@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void conv_fwd_ks_kernel(ConvParams p) {
       for (int w = 0; w < 4; ++w) sacc += rs[(w * 2 + which) * NT * 16 + ch];
       p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
   }
 }
 
@@ -241,7 +242,9 @@ static int launch_conv_ks_cfg(ConvParams p, hipStream_t st) {
   SEGMI_CHECK_ARG(nb < (1ll << 31), "conv3d: too many tiles");
   dim3 grid((unsigned)nb, (unsigned)(p.Cout / (16 * NT)));
   constexpr int red = 4 * 8 * NT * 64 * 16;
-  constexpr int lds = G::LDS_BYTES > red ? G::LDS_BYTES : red;
+  constexpr int lds0 = G::LDS_BYTES > red ? G::LDS_BYTES : red;
+  p.fin_on = p.fin_on && p.stats;
+  const int lds = (int)fin_tail_arm(p, grid, 256, 2 * p.Cout, lds0);
   auto kern = conv_fwd_ks_kernel<T, CK, KS, S, NT, TD, TH, TW>;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {

@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       }
       p.bpart[((int64_t)blockIdx.x * 3 + which) * p.Cout + nt0 * 16 + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.bpart, smem, p.bbfin);
   }
   if (want_stats) {
     float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]  (ring no longer needed)
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
       p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
   }
 }
 
@@ -535,6 +537,9 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
                   "conv3d: sample too large for the ring kernel's 32-bit plane offsets");
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / (16 * NT)));
   p.xcd = xcd != 0 && grid.x % 8 == 0;
+  constexpr bool kStats = (MODE & 2) != 0, kBsum = MODE == 4;
+  p.fin_on = p.fin_on && (kStats || kBsum);
+  (void)fin_tail_arm(p, grid, 256, (kBsum ? 3 : 2) * p.Cout, G::LDS_BYTES + 6 * CK * 4);   // LDS: the ring is larger
   auto kern = conv_ring2_kernel<T, CK, NT, MODE>;
   static bool attr_done = false;
   if (!attr_done && G::LDS_BYTES + 6 * CK * 4 > 64 * 1024) {

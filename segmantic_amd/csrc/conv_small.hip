@@ -7,6 +7,7 @@
 //   wgrad   : MFMA with the voxel axis as K and (ci, tap) as N (see conv_small_wgrad_kernel);
 //             persistent workgroups, per-workgroup partial slabs (deterministic).
 #include "common.h"
+#include "fin_tail.h"
 
 namespace segmi {
 
@@ -27,6 +28,10 @@ struct SmallConvParams {
   const float* bias2;
   int ldo2;
   int vec;   // Cin == 1 rows can be staged with 4-element loads (dense, 4-aligned W and base)
+  // BatchNorm statistics finalised by the last workgroup of this launch (fin_tail.h)
+  int fin_on;
+  FinTail ft;
+  BnFin bfin;
 };
 
 // MFMA forward for tiny Cin:  D[co][vox] += W[co][k] * X[k][vox] with k = ci*27 + tap (the torch
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * 16 + ch];
       p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + co0 + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
   }
 }
 
@@ -466,14 +472,16 @@ template <typename T, int S, int CIN, bool PAIR>
 static int launch_small_fwd_k(SmallConvParams p, hipStream_t st) {
   constexpr int HD = 3 * S + 3, HH = 7 * S + 3, HW = 15 * S + 3, XW = (HW + 6) / 4 * 4;
   constexpr int stage = CIN * HD * HH * XW * (int)sizeof(T);
-  constexpr int lds = stage > 4 * 2 * 16 * 4 ? stage : 4 * 2 * 16 * 4;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
+  constexpr int lds0 = stage > 4 * 2 * 16 * 4 ? stage : 4 * 2 * 16 * 4;
+  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.Cout / 16));
+  p.fin_on = p.fin_on && p.stats;
+  const int lds = (int)fin_tail_arm(p, grid, 256, 2 * p.Cout, lds0);
+  static int attr_set = 0;
+  if (lds > 64 * 1024 && attr_set < lds) {
     (void)hipFuncSetAttribute((const void*)conv_small_fwd_kernel<T, S, CIN, PAIR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_set = lds;
   }
-  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.Cout / 16));
   hipLaunchKernelGGL((conv_small_fwd_kernel<T, S, CIN, PAIR>), grid, 256, lds, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(small-cin)");
   return SEGMI_OK;
@@ -495,8 +503,9 @@ static int launch_small_fwd_cin(const SmallConvParams& p, int cin, hipStream_t s
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
                    const float* bias, const float* alpha, const segmi_act* res, float* stats,
                    int stride, hipStream_t st, const segmi_act* out2, const float* w2,
-                   const float* bias2) {
+                   const float* bias2, const segmi_bn_fin* fin) {
   SmallConvParams p{};
+  if (fin && stats) { p.fin_on = 1; p.bfin = bn_fin_from(fin, out->c); }
   if (out2) { p.out2 = out2->data; p.w2 = w2; p.bias2 = bias2; p.ldo2 = out2->ld; }
   p.vec = in->c == 1 && in->ld == 1 && in->w % 4 == 0 &&
           ((uintptr_t)in->data % (4 * (dtype == SEGMI_F32 ? 4 : 2))) == 0;

@@ -11,6 +11,7 @@
 // as in conv_fwd_impl.h; voxel (z,y,x) of class (rd,rh,rw) lands at (2z+rd, 2y+rh, 2x+rw).
 #pragma once
 #include "common.h"
+#include "fin_tail.h"
 
 namespace segmi {
 
@@ -26,6 +27,10 @@ struct ConvTParams {
   int tz, ty, tx;
   int nchunks, ntiles_total;
   int64_t class_off[8];  // byte offsets of each class in the pack
+  // BatchNorm statistics finalised by the last workgroup of this launch (fin_tail.h)
+  int fin_on;
+  FinTail ft;
+  BnFin bfin;
 };
 
 constexpr int kCtCls[4][3] = {{7, 0, 0}, {3, 5, 0}, {6, 1, 0}, {2, 4, 0}};
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(256) void convt_fwd_mfma_kernel(ConvTParams p) {
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
       p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
   }
 }
 
@@ -337,7 +343,10 @@ static int launch_convt_cfg(ConvTParams p, hipStream_t st) {
   const int64_t nb = (int64_t)p.N * p.tz * p.ty * p.tx;
   SEGMI_CHECK_ARG(nb < (1ll << 31), "convT3d: too many tiles");
   dim3 grid((unsigned)nb, (unsigned)(p.Cout / (16 * NT)));
-  constexpr int lds = G::LDS_BYTES > 4 * 2 * NT * 16 * 4 ? G::LDS_BYTES : 4 * 2 * NT * 16 * 4;
+  constexpr int lds0 = G::LDS_BYTES > 4 * 2 * NT * 16 * 4 ? G::LDS_BYTES : 4 * 2 * NT * 16 * 4;
+  p.fin_on = p.fin_on && p.stats;
+  const int lds = (int)fin_tail_arm(p, grid, 256, 2 * p.Cout, lds0);
+  SEGMI_CHECK_ARG(lds <= 64 * 1024, "convT3d: LDS budget");
   hipLaunchKernelGGL((convt_fwd_mfma_kernel<T, CK, NT, TD, TH, TW>), grid, 256, lds, st, p);
   SEGMI_LAUNCH_CHECK("convT3d_fwd(mfma)");
   return SEGMI_OK;

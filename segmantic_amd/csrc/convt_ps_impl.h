@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTPar
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
       p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + ch] = sacc;
     }
+    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
   }
 }
 
@@ -334,6 +335,9 @@ static int launch_convt_ps_cfg(ConvTParams p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
+  p.fin_on = p.fin_on && p.stats;
+  const size_t lds = fin_tail_arm(p, dim3((unsigned)cdiv(ntiles, per)), 256, 2 * p.Cout, G::LDS_BYTES);
+  SEGMI_CHECK_ARG(lds == (size_t)G::LDS_BYTES, "convT3d: LDS budget");
   hipLaunchKernelGGL((convt_ps_kernel<T, NT, NCH>), cdiv(ntiles, per), 256, G::LDS_BYTES, st, p,
                      ntiles, per);
   SEGMI_LAUNCH_CHECK("convT3d_fwd(persistent)");

@@ -3,12 +3,52 @@
 // 16-byte vectors along the class axis (NDHWC keeps the K classes of a voxel contiguous), the
 // softmax lives in registers, reductions are two-stage and deterministic.
 #include "common.h"
-#include "reduce_fin.h"
+#include "fin_tail.h"
 
 namespace segmi {
 
 constexpr int kDiceVox = 8192;  // voxels per workgroup
 
+
+// one block: per (n,k) sums of the collapsed rows (f64), loss + backward coefficients
+struct DiceFin {
+  int n, k;
+  float smooth_nr, smooth_dr;
+  float *coef, *loss;
+  // sums: [n][3][k] = {intersection, sum p, sum t}
+  __device__ void operator()(const double* sums, double* red) const {
+    const int tid = threadIdx.x;
+    double local = 0.0;
+    const double nk = (double)n * k;
+    for (int o = tid; o < n * k; o += 256) {
+      const int b = o / k, j = o % k;
+      const double* q = sums + ((int64_t)b * 3) * k + j;
+      const double I = q[0], P = q[k], Tt = q[2 * k];
+      // f32 arithmetic as the reference does on the reduced sums
+      const float If = (float)I, Df = (float)Tt + (float)P;
+      const float f = 1.0f - (2.0f * If + smooth_nr) / (Df + smooth_dr);
+      local += (double)f;
+      const double den = (double)Df + (double)smooth_dr;
+      coef[((int64_t)b * 2 + 0) * k + j] = (float)(-2.0 / den / nk);
+      coef[((int64_t)b * 2 + 1) * k + j] = (float)((2.0 * (double)If + (double)smooth_nr) / (den * den) / nk);
+    }
+    red[tid] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) *loss = (float)(red[0] / nk);
+  }
+};
+
+struct ChanSumFin {   // sums: [k] channel sums
+  int k;
+  float* db;
+  __device__ void operator()(const double* sums, double*) const {
+    for (int ch = threadIdx.x; ch < k; ch += blockDim.x) db[ch] = (float)sums[ch];
+  }
+};
 
 struct DiceParams {
   const void* logits;
@@ -21,6 +61,11 @@ struct DiceParams {
   int chunks;
   float grad_scale;
   float* bias_part;  // [n * chunks][k] per-workgroup channel sums of the written gradient (nullable)
+  // finalisation by the last workgroup of the launch (fin_tail.h): forward -> DiceFin over `partials`,
+  // backward -> ChanSumFin over `bias_part`
+  FinTail ft;
+  DiceFin dfin;
+  ChanSumFin cfin;
 };
 
 template <typename T, int KMAX>
@@ -108,39 +153,11 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
                     red[2][which * KMAX + j] + red[3][which * KMAX + j];
     p.partials[(((int64_t)chunk * p.n + n) * 3 + which) * p.k + j] = s;   // [chunk][n][3][k]
   }
-}
-
-// one block: per (n,k) sums of the collapsed rows (f64), loss + backward coefficients
-struct DiceFin {
-  int n, k;
-  float smooth_nr, smooth_dr;
-  float *coef, *loss;
-  // sums: [n][3][k] = {intersection, sum p, sum t}
-  __device__ void operator()(const double* sums, double* red) const {
-    const int tid = threadIdx.x;
-    double local = 0.0;
-    const double nk = (double)n * k;
-    for (int o = tid; o < n * k; o += 256) {
-      const int b = o / k, j = o % k;
-      const double* q = sums + ((int64_t)b * 3) * k + j;
-      const double I = q[0], P = q[k], Tt = q[2 * k];
-      // f32 arithmetic as the reference does on the reduced sums
-      const float If = (float)I, Df = (float)Tt + (float)P;
-      const float f = 1.0f - (2.0f * If + smooth_nr) / (Df + smooth_dr);
-      local += (double)f;
-      const double den = (double)Df + (double)smooth_dr;
-      coef[((int64_t)b * 2 + 0) * k + j] = (float)(-2.0 / den / nk);
-      coef[((int64_t)b * 2 + 1) * k + j] = (float)((2.0 * (double)If + (double)smooth_nr) / (den * den) / nk);
-    }
-    red[tid] = local;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    if (tid == 0) *loss = (float)(red[0] / nk);
+  if (p.ft.on) {
+    extern __shared__ double dice_tail_lds[];
+    fin_tail_run(p.ft, p.partials, dice_tail_lds, p.dfin);
   }
-};
+}
 
 template <typename T, int KMAX, bool FULL>
 __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
@@ -209,6 +226,10 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
     if (tid < p.k)
       p.bias_part[((int64_t)n * p.chunks + chunk) * p.k + tid] =
           (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
+    if (p.ft.on) {
+      extern __shared__ double dice_tail_lds[];
+      fin_tail_run(p.ft, p.bias_part, dice_tail_lds, p.cfin);
+    }
   }
 }
 
@@ -282,14 +303,15 @@ static inline int opt_blocks(int64_t n) {
 template <typename T>
 static int dice_dispatch(bool fwd, const DiceParams& p, hipStream_t st) {
   dim3 grid(p.chunks, p.n);
+  const size_t lds = p.ft.on ? fin_tail_lds(p.ft.width, 256) : 0;
 #define DICE_K(KM)                                                                       \
   do {                                                                                   \
     if (p.k == KM) {                                                                     \
-      if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM, true>), grid, 256, 0, st, p);  \
-      else hipLaunchKernelGGL((dice_bwd_kernel<T, KM, true>), grid, 256, 0, st, p);      \
+      if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM, true>), grid, 256, lds, st, p);  \
+      else hipLaunchKernelGGL((dice_bwd_kernel<T, KM, true>), grid, 256, lds, st, p);      \
     } else {                                                                             \
-      if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM, false>), grid, 256, 0, st, p); \
-      else hipLaunchKernelGGL((dice_bwd_kernel<T, KM, false>), grid, 256, 0, st, p);     \
+      if (fwd) hipLaunchKernelGGL((dice_fwd_kernel<T, KM, false>), grid, 256, lds, st, p); \
+      else hipLaunchKernelGGL((dice_bwd_kernel<T, KM, false>), grid, 256, lds, st, p);     \
     }                                                                                    \
   } while (0)
   if (p.k <= 4) DICE_K(4);
@@ -330,22 +352,12 @@ int segmi_softmax_dice_fwd(int dtype, const segmi_act* logits, const float* labe
   p.vox = (int64_t)logits->d * logits->h * logits->w;
   p.chunks = dice_real_chunks(logits);
   hipStream_t st = (hipStream_t)stream;
-  int rc = dtype == SEGMI_F32 ? dice_dispatch<float>(true, p, st)
-                              : dice_dispatch<bf16_t>(true, p, st);
-  if (rc) return rc;
-  const int width = p.n * 3 * p.k;
-  const DiceFin fin{p.n, p.k, smooth_nr, smooth_dr, coef, loss};
-  return collapse_fin_launch(partials, p.chunks, width, fin_scratch(partials, p.chunks, width), st,
-                             fin, "softmax_dice_fwd(finalize)");
+  // the loss and the backward coefficients are written by the last workgroup of the launch itself
+  // (fin_tail.h): rows = chunks, one row = [n][3][k]
+  p.ft = fin_tail_make(p.chunks, p.n * 3 * p.k, (unsigned)p.chunks * (unsigned)p.n);
+  p.dfin = DiceFin{p.n, p.k, smooth_nr, smooth_dr, coef, loss};
+  return dtype == SEGMI_F32 ? dice_dispatch<float>(true, p, st) : dice_dispatch<bf16_t>(true, p, st);
 }
-
-struct ChanSumFin {   // sums: [k] channel sums
-  int k;
-  float* db;
-  __device__ void operator()(const double* sums, double*) const {
-    for (int ch = threadIdx.x; ch < k; ch += 256) db[ch] = (float)sums[ch];
-  }
-};
 
 int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labels,
                            const float* coef, float grad_scale, const segmi_act* dlogits,
@@ -364,13 +376,11 @@ int segmi_softmax_dice_bwd(int dtype, const segmi_act* logits, const float* labe
   SEGMI_CHECK_ARG(!bias_grad || scratch, "softmax_dice_bwd: bias_grad needs the scratch buffer");
   p.bias_part = bias_grad ? scratch : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = dtype == SEGMI_F32 ? dice_dispatch<float>(false, p, st)
-                                    : dice_dispatch<bf16_t>(false, p, st);
-  if (rc || !bias_grad) return rc;
-  const int rows = p.n * p.chunks;
-  const ChanSumFin fin{p.k, bias_grad};
-  return collapse_fin_launch(scratch, rows, p.k, fin_scratch(scratch, rows, p.k), st, fin,
-                             "softmax_dice_bwd(bias)");
+  if (bias_grad) {   // channel sums of the written gradient, folded by the last workgroup of the launch
+    p.ft = fin_tail_make(p.n * p.chunks, p.k, (unsigned)p.chunks * (unsigned)p.n);
+    p.cfin = ChanSumFin{p.k, bias_grad};
+  }
+  return dtype == SEGMI_F32 ? dice_dispatch<float>(false, p, st) : dice_dispatch<bf16_t>(false, p, st);
 }
 
 int segmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

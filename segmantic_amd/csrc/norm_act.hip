@@ -3,7 +3,7 @@
 // channel axis, per-channel parameters cached in LDS, deterministic two-stage reductions
 // (per-workgroup partials in f32, final reduce in f64) -- no float atomics anywhere.
 #include "common.h"
-#include "reduce_fin.h"
+#include "fin_tail.h"
 
 namespace segmi {
 
@@ -58,6 +58,10 @@ struct EwParams {
   const float* p0; const float* p1; const float* p2; const float* p3; const float* alpha;
   const float* coef;
   float* out_partials;
+  // bn_act_bwd_reduce: finalisation by the last workgroup of the launch (fin_tail.h)
+  int fin_on;
+  FinTail ft;
+  BnBwdFin bbfin;
   // ADN dropout between the norm and the activation (MONAI "NDA"): element kept iff
   // hash(seed, logical NDHWC element index) >> 8 >= drop_thresh (= p * 2^24); kept values are
   // scaled by drop_scale = 1 / (1 - p).  drop_thresh == 0: no dropout.  The mask is never stored:
@@ -149,33 +153,7 @@ int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t 
   return SEGMI_OK;
 }
 
-// [2][c] column sums -> per-channel statistics (the second stage of reduce_fin.h)
-struct BnFin {
-  int c;
-  double count;
-  const float *gamma, *beta;
-  float *running_mean, *running_var;
-  float momentum, eps;
-  float *mean, *invstd, *scale, *shift;
-  __device__ void operator()(const double* sums, double*) const {
-    for (int cc = threadIdx.x; cc < c; cc += 256) {
-      const double m = sums[cc] / count;
-      double var = sums[c + cc] / count - m * m;
-      if (var < 0.0) var = 0.0;
-      const float is = (float)(1.0 / sqrt(var + (double)eps));
-      mean[cc] = (float)m;
-      invstd[cc] = is;
-      const float sc = (gamma ? gamma[cc] : 1.f) * is;
-      scale[cc] = sc;
-      shift[cc] = (beta ? beta[cc] : 0.f) - (float)m * sc;
-      if (running_mean) running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * (float)m;
-      if (running_var) {
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * (float)unb;
-      }
-    }
-  }
-};
+// BnFin / BnBwdFin: fin_tail.h (shared with the kernels that finalise in their own launch)
 
 __global__ void bn_eval_affine_kernel(int c, const float* gamma, const float* beta,
                                       const float* rm, const float* rv, float eps, float* scale,
@@ -291,34 +269,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
     for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 3 * VEC + which * VEC + k];
     p.out_partials[((int64_t)blockIdx.x * 3 + which) * p.c + ch] = acc;
   }
-}
-
-// [3][c] column sums -> dgamma, dbeta, dalpha (sum over channels), coef[2][c] = {mean dz, mean dz*xhat}
-struct BnBwdFin {
-  int c;
-  double count;
-  float *dgamma, *dbeta, *dalpha, *coef;
-  __device__ void operator()(const double* sums, double* red) const {
-    for (int cc = threadIdx.x; cc < c; cc += 256) {
-      const double a0 = sums[cc], a1 = sums[c + cc];
-      if (dbeta) dbeta[cc] = (float)a0;
-      if (dgamma) dgamma[cc] = (float)a1;
-      coef[cc] = (float)(a0 / count);
-      coef[c + cc] = (float)(a1 / count);
-    }
-    if (dalpha) {   // fixed-order sum over channels
-      double t = 0.0;
-      for (int cc = threadIdx.x; cc < c; cc += 256) t += sums[2 * c + cc];
-      red[threadIdx.x] = t;
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {     // fixed-shape tree: deterministic, 8 steps instead of 256
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) *dalpha = (float)red[0];
-    }
+  if (p.ft.on) {
+    extern __shared__ double fin_tail_lds_[];
+    fin_tail_run(p.ft, p.out_partials, fin_tail_lds_, p.bbfin);
   }
-};
+}
 
 // dx = gamma*invstd*(dz - c0 - xhat*c1)
 template <typename T, int VEC>
@@ -492,7 +447,9 @@ int segmi_bn_act_bwd_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) 
 int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
                             const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* prelu_alpha, float* red_partials,
-                            float dropout_p, uint32_t dropout_seed, void* stream) {
+                            float dropout_p, uint32_t dropout_seed, const segmi_bn_bwd_fin* fin,
+                            void* stream) {
+  SEGMI_CHECK_ARG(!fin || (fin->count > 0 && fin->coef), "bn_act_bwd_reduce: fin needs count and coef");
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_act_bwd_reduce: bad dtype");
   SEGMI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "bn_act_bwd_reduce: dropout_p must be in [0, 1)");
   SEGMI_CHECK_ARG(act_ok(dy) && act_ok(x) && same_shape(x, dy) && mean && invstd && red_partials,
@@ -507,7 +464,13 @@ int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
   p.vpw = stat_vox(p.nvox, p.c);
   const bool v4 = vec4_ok(x, dtype) && vec4_ok(dy, dtype);
   const int rows = bn_stats_rows_for(x);
-  DISPATCH_TV(bn_act_bwd_reduce_kernel, dtype, v4, rows, 0, (hipStream_t)stream, p);
+  size_t lds = 0;
+  if (fin) {
+    p.fin_on = 1;
+    p.bbfin = BnBwdFin{x->c, fin->count, fin->dgamma, fin->dbeta, fin->dalpha, fin->coef};
+    lds = fin_tail_arm(p, dim3((unsigned)rows), 256, 3 * x->c, 0);
+  }
+  DISPATCH_TV(bn_act_bwd_reduce_kernel, dtype, v4, rows, lds, (hipStream_t)stream, p);
   SEGMI_LAUNCH_CHECK("bn_act_bwd_reduce");
   return SEGMI_OK;
 }

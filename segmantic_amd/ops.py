@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SEGMI_BF16, SEGMI_F32, Act, BnBwdSums, InAffine, check, lib
+from ._lib import SEGMI_BF16, SEGMI_F32, Act, BnBwdFin, BnBwdSums, BnFin, InAffine, check, lib
 
 _DT = {torch.float32: SEGMI_F32, torch.bfloat16: SEGMI_BF16}
 
@@ -156,24 +156,46 @@ def conv3d_bn_bwd_sums_ok(x, y, ksize, stride) -> bool:
     return bool(lib.segmi_conv3d_bn_bwd_sums_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
 
 
+def _bn_fin(fin):
+    """fin = (count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift)
+    -> byref(segmi_bn_fin) or None: the launch that writes the statistics rows also finalises them"""
+    if fin is None:
+        return None
+    count, gamma, beta, rm, rv, momentum, eps, mean, invstd, scale, shift = fin
+    return C.byref(BnFin(float(count), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), float(momentum), float(eps),
+                         _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift)))
+
+
+def _bn_bwd_fin(fin):
+    """fin = (count, dgamma, dbeta, dalpha, coef) -> segmi_bn_bwd_fin or None"""
+    if fin is None:
+        return None
+    count, dgamma, dbeta, dalpha, coef = fin
+    return BnBwdFin(float(count), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(coef))
+
+
 def conv3d_fwd(x, y, packed, w_src, w_kind, bias, ksize, stride, prelu_alpha=None,
-               residual=None, stats=None, in_tf=None, bn_bwd=None) -> None:
+               residual=None, stats=None, in_tf=None, bn_bwd=None, stats_fin=None, bn_bwd_fin=None) -> None:
     """``in_tf`` = (scale, shift, alpha): the producer's BatchNorm-apply + PReLU is applied to ``x``
     while it is staged (segmi_in_affine; only where ``conv3d_in_affine_ok``).
     ``bn_bwd`` = (x_raw, mean, invstd, gamma, beta, alpha | None, partials): this launch is an
     input-gradient conv whose output flows into that BatchNorm + PReLU; its epilogue also writes the
-    partial rows of the BatchNorm-backward reduction (segmi_bn_bwd_sums; where ``conv3d_bn_bwd_sums_ok``)."""
+    partial rows of the BatchNorm-backward reduction (segmi_bn_bwd_sums; where ``conv3d_bn_bwd_sums_ok``).
+    ``stats_fin`` / ``bn_bwd_fin``: the launch also finalises the ``stats`` / ``bn_bwd`` rows (``_bn_fin``,
+    ``_bn_bwd_fin``): no separate bn_finalize / bn_act_bwd_finalize launch."""
     ax, ay = act(x), act(y)
     ar = act(residual) if residual is not None else None
     bb = None
     if bn_bwd is not None:
         xr, mean, invstd, gamma, beta, alpha, part = bn_bwd
         abx = act(xr)
+        bf = _bn_bwd_fin(bn_bwd_fin)
         bb = C.byref(BnBwdSums(C.pointer(abx), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha),
-                               _ptr(part)))
+                               _ptr(part), C.pointer(bf) if bf is not None else None))
     check(lib.segmi_conv3d_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed),
                                _ptr(w_src), w_kind, _ptr(bias), _ptr(prelu_alpha), _ref(ar),
-                               _ptr(stats), ksize, stride, _in_affine(in_tf), bb, _stream()), "conv3d_fwd")
+                               _ptr(stats), ksize, stride, _in_affine(in_tf), bb, _bn_fin(stats_fin), _stream()),
+          "conv3d_fwd")
 
 
 def dectop_ok(x, y) -> bool:
@@ -202,12 +224,12 @@ def conv3d_pair_ok(x, y_a, y_b) -> bool:
 
 
 def conv3d_fwd_pair(x, y_a, w_a, bias_a, y_b, w_b, bias_b, stride, prelu_alpha_a=None,
-                    stats_a=None) -> None:
+                    stats_a=None, stats_fin_a=None) -> None:
     """Subunit-0 and residual convolution of a small-Cin ResidualUnit in one launch."""
     ax, aa, ab = act(x), act(y_a), act(y_b)
     check(lib.segmi_conv3d_fwd_pair(dtype_code(x), C.byref(ax), C.byref(aa), _ptr(w_a), _ptr(bias_a),
                                     _ptr(prelu_alpha_a), _ptr(stats_a), C.byref(ab), _ptr(w_b),
-                                    _ptr(bias_b), stride, _stream()), "conv3d_fwd_pair")
+                                    _ptr(bias_b), stride, _bn_fin(stats_fin_a), _stream()), "conv3d_fwd_pair")
 
 
 def conv3d_split_act_ok(x, y, ksize, stride) -> bool:
@@ -228,12 +250,13 @@ def convT3d_stats_rows(x, y) -> int:
     return int(lib.segmi_convT3d_stats_rows(dtype_code(x), C.byref(ax), C.byref(ay)))
 
 
-def convT3d_fwd(x, y, packed, w_src, bias, prelu_alpha=None, residual=None, stats=None) -> None:
+def convT3d_fwd(x, y, packed, w_src, bias, prelu_alpha=None, residual=None, stats=None,
+                stats_fin=None) -> None:
     ax, ay = act(x), act(y)
     ar = act(residual) if residual is not None else None
     check(lib.segmi_convT3d_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed),
                                 _ptr(w_src), _ptr(bias), _ptr(prelu_alpha), _ref(ar),
-                                _ptr(stats), _stream()), "convT3d_fwd")
+                                _ptr(stats), _bn_fin(stats_fin), _stream()), "convT3d_fwd")
 
 
 def conv3d_wgrad_workspace(x, dy, ksize, stride) -> int:
@@ -296,12 +319,14 @@ def bn_act_bwd_rows(x) -> int:
 
 
 def bn_act_bwd_reduce(dy, x, mean, invstd, gamma, beta, prelu_alpha, partials,
-                      dropout=(0.0, 0)) -> None:
+                      dropout=(0.0, 0), fin=None) -> None:
+    """``fin`` = (count, dgamma, dbeta, dalpha, coef): finalise in the same launch"""
     ady, ax = act(dy), act(x)
+    bf = _bn_bwd_fin(fin)
     check(lib.segmi_bn_act_bwd_reduce(dtype_code(x), C.byref(ady), C.byref(ax), _ptr(mean),
                                       _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(prelu_alpha),
                                       _ptr(partials), float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF,
-                                      _stream()), "bn_act_bwd_reduce")
+                                      C.byref(bf) if bf is not None else None, _stream()), "bn_act_bwd_reduce")
 
 
 def bn_act_bwd_finalize(partials, rows, c, count, gamma, invstd, dgamma, dbeta, dalpha,

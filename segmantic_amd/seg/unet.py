@@ -589,16 +589,24 @@ class UNetEngine:
             rows = (ops.convT3d_stats_rows(x, y) if conv.transposed
                     else ops.conv3d_stats_rows(x, y, conv.k, conv.stride))
             stats = self._fstat(rows, conv.cout)
+        # the launch that writes the statistics rows finalises them itself (segmi_bn_fin): no
+        # bn_finalize launch on the dependent chain (SEGMI_FUSE_FIN=0: separate launch, for A/B)
+        fin = self._stats_fin(bn, y) if bn is not None and self.fuse_fin else None
         if conv.transposed:
             self._timed(conv.prefix + ":fwd", ops.convT3d_fwd, x, y, conv.fwd_pack(), conv.w,
-                        conv.b, stats=stats)
+                        conv.b, stats=stats, stats_fin=fin)
         else:
             self._timed(conv.prefix + ":fwd", ops.conv3d_fwd, x, y, conv.fwd_pack(), conv.w, 0,
-                        conv.b, conv.k, conv.stride, stats=stats, in_tf=in_tf)
-        if bn is not None:
+                        conv.b, conv.k, conv.stride, stats=stats, in_tf=in_tf, stats_fin=fin)
+        if bn is not None and fin is None:
             count = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
             ops.bn_finalize(stats, rows, conv.cout, count, bn.gamma, bn.beta, bn.rm, bn.rv,
                             self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
+
+    def _stats_fin(self, bn: "_BN", y) -> tuple:
+        count = y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
+        return (count, bn.gamma, bn.beta, bn.rm, bn.rv, self.momentum, self.eps, bn.mean, bn.invstd,
+                bn.scale, bn.shift)
 
     def _wgrad(self, conv: _Conv, x, dy, need_bias: bool = True, in_tf=None):
         """dW (and db) of `conv` given its forward input x and output gradient dy.
@@ -651,7 +659,8 @@ class UNetEngine:
             part = self._fstat(rows, bn.c)
             self._timed(conv.prefix + ":dgrad", ops.conv3d_fwd, dy, dx, conv.dgrad_pack(), conv.w, 1,
                         None, conv.k, 1, residual=residual,
-                        bn_bwd=(x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part))
+                        bn_bwd=(x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part),
+                        bn_bwd_fin=self._bwd_fin(bn, x_raw) if self.fuse_fin else None)
             return rows
         if conv.transposed:
             ops.conv3d_fwd(dy, dx, conv.dgrad_pack(), conv.w, 0, None, 3, 2, residual=residual)
@@ -660,6 +669,11 @@ class UNetEngine:
         else:
             self._timed(conv.prefix + ":dgrad", ops.conv3d_fwd, dy, dx, conv.dgrad_pack(), conv.w, 1,
                         None, conv.k, 1, residual=residual)
+
+    @staticmethod
+    def _bwd_fin(bn: "_BN", x_raw) -> tuple:
+        count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
+        return (count, bn.g_gamma, bn.g_beta, bn.g_alpha, bn.coef)
 
     def _bn_bwd(self, bn: _BN, dy, x_raw, dx, sums_rows: int = 0):
         """``sums_rows`` > 0: the reduction's partial rows were written by the launch that produced dy
@@ -672,9 +686,10 @@ class UNetEngine:
             rows = ops.bn_act_bwd_rows(x_raw)
             part = self._fstat(rows, bn.c)
             ops.bn_act_bwd_reduce(dy, x_raw, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, part,
-                                  dropout=bn.drop())
-        ops.bn_act_bwd_finalize(part, rows, bn.c, count, bn.gamma, bn.invstd, bn.g_gamma,
-                                bn.g_beta, bn.g_alpha, bn.coef)
+                                  dropout=bn.drop(), fin=self._bwd_fin(bn, x_raw) if self.fuse_fin else None)
+        if not self.fuse_fin:         # else: finalised by the launch that wrote the rows
+            ops.bn_act_bwd_finalize(part, rows, bn.c, count, bn.gamma, bn.invstd, bn.g_gamma,
+                                    bn.g_beta, bn.g_alpha, bn.coef)
         ops.bn_act_bwd_apply(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
                              bn.coef, dropout=bn.drop())
 
@@ -711,10 +726,12 @@ class UNetEngine:
                 rows = ops.conv3d_stats_rows(x, r, conv.k, conv.stride)
                 stats = self._fstat(rows, conv.cout)
                 rc = ru["res"]
+                fin = self._stats_fin(bn, r) if self.fuse_fin else None
                 self._timed(conv.prefix + ":fwd", ops.conv3d_fwd_pair, x, r, conv.w, conv.b, out,
-                            rc.w, rc.b, conv.stride, stats_a=stats)
-                ops.bn_finalize(stats, rows, conv.cout, n * d * h * w, bn.gamma, bn.beta, bn.rm,
-                                bn.rv, self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
+                            rc.w, rc.b, conv.stride, stats_a=stats, stats_fin_a=fin)
+                if fin is None:
+                    ops.bn_finalize(stats, rows, conv.cout, n * d * h * w, bn.gamma, bn.beta, bn.rm,
+                                    bn.rv, self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
                 saved[f"in{i}"] = cur
                 saved[f"r{i}"] = r
                 nconv = ru["units"][i + 1][0]
@@ -1101,6 +1118,9 @@ class UNetEngine:
     # BatchNorm-apply + PReLU folded into the consumer conv's staging where the kernels allow it
     # (segmi_in_affine); SEGMI_FUSE_BN=0 keeps the separate pass for A/B measurements
     fuse_bn_apply = os.environ.get("SEGMI_FUSE_BN", "1") != "0"
+    # Finalisation of every BatchNorm reduction (forward statistics, backward sums) by the launch that
+    # writes the partial rows (csrc/fin_tail.h); SEGMI_FUSE_FIN=0 keeps the separate one-workgroup launches
+    fuse_fin = os.environ.get("SEGMI_FUSE_FIN", "1") != "0"
     # BatchNorm-backward reduction in the epilogue of the input-gradient launch that produces its
     # operand (segmi_bn_bwd_sums); SEGMI_FUSE_BN_BWD=0 keeps the separate two-tensor pass (A/B)
     fuse_bn_bwd = os.environ.get("SEGMI_FUSE_BN_BWD", "1") != "0"

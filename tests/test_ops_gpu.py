@@ -1185,3 +1185,171 @@ def test_wave_specialised_wgrad_matches_torch(case):
     ops.conv3d_wgrad(wide[..., cin:], dyd, dw, None, k, s, ws)
     torch.cuda.synchronize()
     assert relerr(dw.cpu(), w0.grad) < 5e-5
+
+
+# ------------------------------------------------------------------ finalisation inside the producing launch
+def _fin_bufs(c, seed=0):
+    rm = (rnd((c,), 900 + seed) * 0.2).to(DEV)
+    rv = (rnd((c,), 901 + seed).abs() + 0.5).to(DEV)
+    outs = [torch.full((c,), float("nan"), device=DEV) for _ in range(4)]
+    return rm, rv, outs
+
+
+FIN_CONV_CASES = [
+    # cin, cout, k, s, spatial, batch, transposed       kernel family
+    (16, 16, 3, 1, (16, 64, 128), 4, False),           # z-marching ring
+    (32, 32, 3, 1, (33, 60, 120), 2, False),           # ring, CK = 32, two tiles
+    (64, 64, 3, 1, (9, 10, 40), 2, False),             # k-split
+    (256, 32, 3, 1, (8, 8, 8), 1, False),              # k-split, deep
+    (16, 32, 3, 2, (10, 12, 36), 1, False),            # tile kernel, stride 2
+    (128, 256, 1, 1, (4, 4, 4), 2, False),             # tile kernel, k1
+    (1, 16, 3, 2, (20, 34, 70), 1, False),             # small-Cin
+    (16, 3, 3, 1, (6, 7, 9), 1, False),                # direct kernel + bn_stats (separate finalisation inside the call)
+    (32, 16, 3, 2, (8, 16, 32), 2, True),              # transposed, persistent parity-class kernel
+    (128, 32, 3, 2, (4, 4, 8), 1, True),               # transposed, tile kernel
+    (384, 64, 3, 2, (2, 2, 2), 2, True),               # transposed, deep
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FIN_CONV_CASES)
+def test_bn_statistics_finalised_by_the_producing_launch(case, dtype):
+    """segmi_bn_fin (csrc/fin_tail.h): the convolution that writes the statistics rows also finalises
+    them -- mean / invstd / scale / shift / running statistics equal the separate segmi_bn_finalize
+    launch on the same rows (f64 sums of the same f32 rows in another fixed order: <= 1e-6 relative),
+    the output tensor is bit-identical, and the result is bitwise reproducible run to run."""
+    cin, cout, k, s, sp, n, transposed = case
+    x = rnd((n, cin) + sp, 11)
+    xd = to_ndhwc(x, dtype)
+    if transposed:
+        w = rnd((cin, cout, 3, 3, 3), 12, 1.0 / math.sqrt(cin * 27 / 8))
+        osp = tuple(2 * v for v in sp)
+        kind = 2
+    else:
+        w = rnd((cout, cin, k, k, k), 12, 1.0 / math.sqrt(cin * k ** 3))
+        osp = tuple((v + 2 * ((k - 1) // 2) - k) // s + 1 for v in sp)
+        kind = 0
+    b = rnd((cout,), 13, 0.1).to(DEV)
+    wd = w.to(DEV)
+    packed = ops.wpack(dtype, kind, wd, cin, cout, 3 if transposed else k) if ops.mfma_ok(cin, cout) else None
+    gamma, beta = (1 + 0.2 * rnd((cout,), 14)).to(DEV), (0.1 * rnd((cout,), 15)).to(DEV)
+    count = n * osp[0] * osp[1] * osp[2]
+
+    def run(fused):
+        y = torch.empty((n,) + osp + (cout,), dtype=dtype, device=DEV)
+        rows = ops.convT3d_stats_rows(xd, y) if transposed else ops.conv3d_stats_rows(xd, y, k, s)
+        stats = torch.zeros((rows, 2, cout), device=DEV)
+        rm, rv, (mean, invstd, scale, shift) = _fin_bufs(cout)
+        fin = (count, gamma, beta, rm, rv, 0.1, 1e-5, mean, invstd, scale, shift)
+        if transposed:
+            ops.convT3d_fwd(xd, y, packed, wd, b, stats=stats, stats_fin=fin if fused else None)
+        else:
+            ops.conv3d_fwd(xd, y, packed, wd, 0, b, k, s, stats=stats, stats_fin=fin if fused else None)
+        if not fused:
+            ops.bn_finalize(stats, rows, cout, count, gamma, beta, rm, rv, 0.1, 1e-5, mean, invstd, scale, shift)
+        torch.cuda.synchronize()
+        return y, [t.clone() for t in (mean, invstd, scale, shift, rm, rv)]
+
+    y0, ref = run(False)
+    y1, got = run(True)
+    y2, again = run(True)
+    assert torch.equal(y0, y1)
+    for a, g_, g2, name in zip(ref, got, again, ("mean", "invstd", "scale", "shift", "running_mean", "running_var")):
+        assert bool(torch.isfinite(g_).all()), name
+        assert float((a - g_).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, name
+        assert torch.equal(g_, g2), name + " not reproducible"
+
+
+def test_bn_statistics_finalised_by_the_pair_launch():
+    cin, cout, sp, n, s = 1, 16, (20, 34, 70), 2, 2
+    dtype = torch.bfloat16
+    xd = to_ndhwc(rnd((n, cin) + sp, 21), dtype)
+    wa, wb = rnd((cout, cin, 3, 3, 3), 22, 0.2).to(DEV), rnd((cout, cin, 3, 3, 3), 23, 0.2).to(DEV)
+    ba, bb = rnd((cout,), 24, 0.1).to(DEV), rnd((cout,), 25, 0.1).to(DEV)
+    osp = tuple((v - 1) // 2 + 1 for v in sp)
+    count = n * osp[0] * osp[1] * osp[2]
+    gamma, beta = (1 + 0.2 * rnd((cout,), 26)).to(DEV), (0.1 * rnd((cout,), 27)).to(DEV)
+
+    def run(fused):
+        ya = torch.empty((n,) + osp + (cout,), dtype=dtype, device=DEV)
+        yb = torch.empty_like(ya)
+        assert ops.conv3d_pair_ok(xd, ya, yb)
+        rows = ops.conv3d_stats_rows(xd, ya, 3, s)
+        stats = torch.zeros((rows, 2, cout), device=DEV)
+        rm, rv, (mean, invstd, scale, shift) = _fin_bufs(cout)
+        fin = (count, gamma, beta, rm, rv, 0.1, 1e-5, mean, invstd, scale, shift)
+        ops.conv3d_fwd_pair(xd, ya, wa, ba, yb, wb, bb, s, stats_a=stats, stats_fin_a=fin if fused else None)
+        if not fused:
+            ops.bn_finalize(stats, rows, cout, count, gamma, beta, rm, rv, 0.1, 1e-5, mean, invstd, scale, shift)
+        torch.cuda.synchronize()
+        return ya, yb, [t.clone() for t in (mean, invstd, scale, shift, rm, rv)]
+
+    a0, b0, ref = run(False)
+    a1, b1, got = run(True)
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    for a, g_ in zip(ref, got):
+        assert float((a - g_).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,sp,n", [(16, (16, 64, 64), 2), (64, (9, 10, 12), 2), (256, (8, 8, 8), 1), (3, (5, 6, 7), 2)])
+def test_bn_backward_sums_finalised_by_the_reduce_launch(c, sp, n, dtype):
+    x = rnd((n, c) + sp, 31, 2.0)
+    dy = rnd((n, c) + sp, 32)
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    mean = (rnd((c,), 33) * 0.5).to(DEV)
+    invstd = (rnd((c,), 34).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd((c,), 35) + 1.5).to(DEV), (rnd((c,), 36) * 0.3).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV)
+    count = n * sp[0] * sp[1] * sp[2]
+    rows = ops.bn_act_bwd_rows(xd)
+
+    def run(fused):
+        part = torch.zeros((rows, 3, c), device=DEV)
+        dg, db, da = (torch.full((m,), float("nan"), device=DEV) for m in (c, c, 1))
+        coef = torch.full((2, c), float("nan"), device=DEV)
+        ops.bn_act_bwd_reduce(dyd, xd, mean, invstd, gamma, beta, alpha, part,
+                              fin=(count, dg, db, da, coef) if fused else None)
+        if not fused:
+            ops.bn_act_bwd_finalize(part, rows, c, count, gamma, invstd, dg, db, da, coef)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (dg, db, da, coef)]
+
+    ref, got, again = run(False), run(True), run(True)
+    for a, g_, g2, name in zip(ref, got, again, ("dgamma", "dbeta", "dalpha", "coef")):
+        assert bool(torch.isfinite(g_).all()), name
+        assert float((a - g_).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, name
+        assert torch.equal(g_, g2), name
+
+
+def test_bn_backward_sums_finalised_by_the_input_gradient_launch():
+    """ring kernel MODE 4 (segmi_bn_bwd_sums) with its `fin`: the launch that produces the gradient and the
+    partial rows also writes dgamma / dbeta / dalpha / coef"""
+    n, d, h, w, c = 2, 32, 64, 128, 16
+    dyd = to_ndhwc(rnd((n, c, d, h, w), 41, 0.5), torch.bfloat16)
+    xd = to_ndhwc(rnd((n, c, d, h, w), 42, 2.0) + 0.3, torch.bfloat16)
+    pk = ops.wpack(torch.bfloat16, 1, rnd((c, c, 3, 3, 3), 43, 0.08).to(DEV), c, c, 3)
+    mean, invstd = (rnd((c,), 44) * 0.5).to(DEV), (rnd((c,), 45).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd((c,), 46) + 1.5).to(DEV), (rnd((c,), 47) * 0.3).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV)
+    count = n * d * h * w
+
+    def run(fused):
+        dx = torch.empty_like(dyd)
+        rows = ops.conv3d_stats_rows(dyd, dx, 3, 1)
+        part = torch.zeros((rows, 3, c), device=DEV)
+        dg, db, da = (torch.full((m,), float("nan"), device=DEV) for m in (c, c, 1))
+        coef = torch.full((2, c), float("nan"), device=DEV)
+        ops.conv3d_fwd(dyd, dx, pk, None, 1, None, 3, 1, bn_bwd=(xd, mean, invstd, gamma, beta, alpha, part),
+                       bn_bwd_fin=(count, dg, db, da, coef) if fused else None)
+        if not fused:
+            ops.bn_act_bwd_finalize(part, rows, c, count, gamma, invstd, dg, db, da, coef)
+        torch.cuda.synchronize()
+        return dx, [t.clone() for t in (dg, db, da, coef)]
+
+    dx0, ref = run(False)
+    dx1, got = run(True)
+    assert torch.equal(dx0, dx1)
+    for a, g_, name in zip(ref, got, ("dgamma", "dbeta", "dalpha", "coef")):
+        assert bool(torch.isfinite(g_).all()), name
+        assert float((a - g_).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, name
