@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void conv_fwd_ks_kernel(ConvParams p) {
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sacc += rs[(w * 2 + which) * NT * 16 + ch];
-      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
+      fin_store(&p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch], sacc);
     }
-    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
+    fin_tail_run<BnFin, 256, offsetof(ConvParams, ft), offsetof(ConvParams, bfin)>(p.stats, smem);
   }
 }
 

@@ -485,9 +485,9 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
         for (int w = 0; w < 4; ++w) s0 += red[(w * 3 + 0) * NT * 16 + ch];
         sacc = bprm[1 * NT * 16 + ch] * fmaf(-bprm[ch], s0, sacc);
       }
-      p.bpart[((int64_t)blockIdx.x * 3 + which) * p.Cout + nt0 * 16 + ch] = sacc;
+      fin_store(&p.bpart[((int64_t)blockIdx.x * 3 + which) * p.Cout + nt0 * 16 + ch], sacc);
     }
-    if (p.ft.on) fin_tail_run(p.ft, p.bpart, smem, p.bbfin);
+    fin_tail_run<BnBwdFin, 256, offsetof(ConvParams, ft), offsetof(ConvParams, bbfin)>(p.bpart, smem);
   }
   if (want_stats) {
     float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]  (ring no longer needed)
@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
-      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch] = sacc;
+      fin_store(&p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch], sacc);
     }
-    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
+    fin_tail_run<BnFin, 256, offsetof(ConvParams, ft), offsetof(ConvParams, bfin)>(p.stats, smem);
   }
 }
 

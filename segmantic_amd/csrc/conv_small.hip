@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * 16 + ch];
-      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + co0 + ch] = sacc;
+      fin_store(&p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + co0 + ch], sacc);
     }
-    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
+    fin_tail_run<BnFin, 256, offsetof(SmallConvParams, ft), offsetof(SmallConvParams, bfin)>(p.stats, smem);
   }
 }
 

@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void convt_ps_kernel(ConvTPar
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
-      p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + ch] = sacc;
+      fin_store(&p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + ch], sacc);
     }
-    if (p.ft.on) fin_tail_run(p.ft, p.stats, smem, p.bfin);
+    fin_tail_run<BnFin, 256, offsetof(ConvTParams, ft), offsetof(ConvTParams, bfin)>(p.stats, smem);
   }
 }
 

@@ -8,7 +8,7 @@
 // ticket folds the whole table in a fixed order (f64) and runs the finalisation functor -- in the
 // same launch.  The result does not depend on which workgroup arrives last: the fold order is a
 // function of (rows, width, threads) only, so the reduction stays bitwise reproducible without float
-// atomics.  (The values can differ in the last bit from the two-stage collapse_fin_kernel, which
+// atomics.  All kernels that carry a tail run 256-thread workgroups.  (The values can differ in the last bit from the two-stage collapse_fin_kernel, which
 // folds 64 f64 rows: both are exact-to-f64 sums of the same f32 rows in different orders.)
 //
 // Ticket counters: reduce_fin.h's per-translation-unit g_fin_tickets (integer, self-resetting,
@@ -51,65 +51,99 @@ static inline size_t fin_tail_arm(P& p, dim3 grid, int threads, int width, size_
   return lds > need ? lds : need;
 }
 
-// To be called by ALL threads of the workgroup, after the workgroup's own rows have been stored and
-// when its LDS is free.  Returns true in the (single) workgroup that ran the finalisation.
-template <class Fin>
-__device__ __forceinline__ bool fin_tail_run(const FinTail& ft, const float* __restrict__ partials,
-                                             void* lds, const Fin& fin) {
+// ------------------------------------------------------------------ device side
+// Cross-XCD visibility WITHOUT cache-wide fences.  A __threadfence() (release at agent scope) makes
+// gfx950 write back every dirty line of the XCD's L2 (buffer_wbl2): issued by each of the thousands
+// of workgroups of a convolution that is streaming its output through that L2, it costs ~80 us per
+// launch (measured: 9.3 vs 6.5 ms per training step).  Instead the few floats that have to cross
+// XCDs are moved with agent-scope relaxed atomics -- write-through stores (sc1) and coherent loads
+// -- and ordered by hand: every thread waits for its own stores (workgroup-scope release = s_waitcnt
+// vmcnt(0)), the workgroup barrier collects the waves, one thread takes the ticket.
+__device__ __forceinline__ void fin_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fin_load2(const float* p, float& a, float& b) {   // 8-byte aligned
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = __uint_as_float((unsigned)u);
+  b = __uint_as_float((unsigned)(u >> 32));
+}
+__device__ __forceinline__ float fin_load1(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A field of the kernel's by-value parameter struct (first kernel argument = offset 0 of the kernarg
+// segment), read HERE and not at kernel entry: the finalisation descriptors (a dozen pointers) must
+// not occupy SGPRs for the whole lifetime of a register-bound MFMA kernel (with the fields read
+// through `p.` hipcc hoists the s_loads to the top: 83 -> 101 SGPRs, VGPR spills of SGPRs, one
+// k-split variant beyond 256 VGPRs).
+template <class T>
+__device__ __forceinline__ T kernarg_late(unsigned offset) {
+  const __attribute__((address_space(4))) char* ka =
+      (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  T v;
+  __builtin_memcpy(&v, (const char*)ka + offset, sizeof(T));
+  return v;
+}
+
+// To be called by ALL NT threads of the workgroup, after the workgroup's own rows have been stored
+// with fin_store() and when its LDS is free (needs fin_tail_lds(width, NT) bytes behind `lds`).
+// Returns true in the (single) workgroup that ran the finalisation.  FT_OFF / FIN_OFF: offsetof the
+// FinTail / functor members in the kernel's parameter struct (see kernarg_late).
+template <class Fin, int NT, unsigned FT_OFF, unsigned FIN_OFF>
+__device__ __forceinline__ bool fin_tail_run(const float* __restrict__ partials, void* lds) {
+  const FinTail ft = kernarg_late<FinTail>(FT_OFF);
+  if (!ft.on) return false;
   __shared__ int s_fin_last;
-  const int nt = blockDim.x, tid = threadIdx.x;
-  __threadfence();   // release: this workgroup's rows are visible device-wide (all XCDs)
+  const int tid = threadIdx.x;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's row stores have completed
   __syncthreads();
   if (tid == 0) {
-    const unsigned prev = atomicAdd(&g_fin_tickets[ft.ticket], 1u);
+    const unsigned prev = __hip_atomic_fetch_add(&g_fin_tickets[ft.ticket], 1u, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
     s_fin_last = prev == ft.nwg - 1;
-    if (s_fin_last) g_fin_tickets[ft.ticket] = 0;   // ready for the next launch that draws this ticket
+    if (s_fin_last)     // ready for the next launch that draws this ticket
+      __hip_atomic_store(&g_fin_tickets[ft.ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!s_fin_last) return false;
-  __threadfence();   // acquire: the other workgroups' rows
   double* sums = reinterpret_cast<double*>(lds);            // [width]
-  double* red = sums + ft.width;                            // [4 * nt]
+  double* red = sums + ft.width;                            // [4 * NT]
   const int rows = ft.rows, width = ft.width;
-  const bool vec4 = width % 4 == 0 && width / 4 <= nt && ((uintptr_t)partials & 15) == 0;
-  if (vec4) {
-    const int wl4 = width / 4, rl4 = nt / wl4;
-    const int col4 = tid % wl4, lane4 = tid / wl4;
-    double s[2][4];
+  const bool vec2 = width % 2 == 0 && width / 2 <= NT && ((uintptr_t)partials & 7) == 0;
+  if (vec2) {
+    const int wl2 = width / 2, rl2 = NT / wl2;
+    const int col2 = tid % wl2, lane2 = tid / wl2;
+    double s[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    if (lane2 < rl2) {
+      const float* src = partials + 2 * col2;
+      int r = lane2;
+      for (; r + 15 * rl2 < rows; r += 16 * rl2) {            // 16 x 8-byte coherent loads in flight per thread
+        float a[16], b[16];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < 16; ++u) fin_load2(src + (int64_t)(r + u * rl2) * width, a[u], b[u]);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) s[a][b] = 0.0;
-    if (lane4 < rl4) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(partials) + col4;
-      int r = lane4;
-      for (; r + 7 * rl4 < rows; r += 8 * rl4) {             // 8 x 16-byte loads in flight per thread
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (int64_t)(r + u * rl4) * wl4);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) s[u & 1][b] += (double)v[u][b];
+        for (int u = 0; u < 16; ++u) { s[u & 1][0] += (double)a[u]; s[u & 1][1] += (double)b[u]; }
       }
-      for (; r < rows; r += rl4) {
-        const f32x4 v = __builtin_nontemporal_load(src + (int64_t)r * wl4);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) s[0][b] += (double)v[b];
+      for (; r < rows; r += rl2) {
+        float a, b;
+        fin_load2(src + (int64_t)r * width, a, b);
+        s[0][0] += (double)a; s[0][1] += (double)b;
       }
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) red[tid * 4 + b] = s[0][b] + s[1][b];
+    red[tid * 2 + 0] = s[0][0] + s[1][0];
+    red[tid * 2 + 1] = s[0][1] + s[1][1];
     __syncthreads();
-    for (int e = tid; e < width; e += nt) {
-      const int c4 = e / 4, b = e % 4;
+    for (int e = tid; e < width; e += NT) {
+      const int c2 = e / 2, b = e % 2;
       double t = 0.0;
-      for (int l = 0; l < rl4; ++l) t += red[(l * wl4 + c4) * 4 + b];
+      for (int l = 0; l < rl2; ++l) t += red[(l * wl2 + c2) * 2 + b];
       sums[e] = t;
     }
   } else {
-    const int wl = width < nt ? width : nt;
-    const int rl = nt / wl;
+    const int wl = width < NT ? width : NT;
+    const int rl = NT / wl;
     const int col = tid % wl, lane = tid / wl;
     for (int w0 = 0; w0 < width; w0 += wl) {
       const int e = w0 + col;
@@ -119,11 +153,11 @@ __device__ __forceinline__ bool fin_tail_run(const FinTail& ft, const float* __r
         for (; r + 7 * rl < rows; r += 8 * rl) {
           float v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(partials + (int64_t)(r + u * rl) * width + e);
+          for (int u = 0; u < 8; ++u) v[u] = fin_load1(partials + (int64_t)(r + u * rl) * width + e);
 #pragma unroll
           for (int u = 0; u < 8; u += 2) { s0 += (double)v[u]; s1 += (double)v[u + 1]; }
         }
-        for (; r < rows; r += rl) s0 += (double)__builtin_nontemporal_load(partials + (int64_t)r * width + e);
+        for (; r < rows; r += rl) s0 += (double)fin_load1(partials + (int64_t)r * width + e);
       }
       red[tid] = s0 + s1;
       __syncthreads();
@@ -136,6 +170,7 @@ __device__ __forceinline__ bool fin_tail_run(const FinTail& ft, const float* __r
     }
   }
   __syncthreads();
+  const Fin fin = kernarg_late<Fin>(FIN_OFF);
   fin(sums, red);
   return true;
 }
@@ -151,7 +186,7 @@ struct BnFin {
   float momentum, eps;
   float *mean, *invstd, *scale, *shift;
   __device__ void operator()(const double* sums, double*) const {
-    for (int cc = threadIdx.x; cc < c; cc += blockDim.x) {
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
       const double m = sums[cc] / count;
       double var = sums[c + cc] / count - m * m;
       if (var < 0.0) var = 0.0;
@@ -176,8 +211,7 @@ struct BnBwdFin {
   double count;
   float *dgamma, *dbeta, *dalpha, *coef;
   __device__ void operator()(const double* sums, double* red) const {
-    const int nt = blockDim.x;
-    for (int cc = threadIdx.x; cc < c; cc += nt) {
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
       const double a0 = sums[cc], a1 = sums[c + cc];
       if (dbeta) dbeta[cc] = (float)a0;
       if (dgamma) dgamma[cc] = (float)a1;

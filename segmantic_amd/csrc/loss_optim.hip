@@ -46,7 +46,7 @@ struct ChanSumFin {   // sums: [k] channel sums
   int k;
   float* db;
   __device__ void operator()(const double* sums, double*) const {
-    for (int ch = threadIdx.x; ch < k; ch += blockDim.x) db[ch] = (float)sums[ch];
+    for (int ch = threadIdx.x; ch < k; ch += 256) db[ch] = (float)sums[ch];
   }
 };
 
@@ -151,11 +151,11 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
     const int which = tid / p.k, j = tid % p.k;
     const float s = red[0][which * KMAX + j] + red[1][which * KMAX + j] +
                     red[2][which * KMAX + j] + red[3][which * KMAX + j];
-    p.partials[(((int64_t)chunk * p.n + n) * 3 + which) * p.k + j] = s;   // [chunk][n][3][k]
+    fin_store(&p.partials[(((int64_t)chunk * p.n + n) * 3 + which) * p.k + j], s);   // [chunk][n][3][k]
   }
-  if (p.ft.on) {
+  {
     extern __shared__ double dice_tail_lds[];
-    fin_tail_run(p.ft, p.partials, dice_tail_lds, p.dfin);
+    fin_tail_run<DiceFin, 256, offsetof(DiceParams, ft), offsetof(DiceParams, dfin)>(p.partials, dice_tail_lds);
   }
 }
 
@@ -224,11 +224,11 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
     }
     __syncthreads();
     if (tid < p.k)
-      p.bias_part[((int64_t)n * p.chunks + chunk) * p.k + tid] =
-          (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
-    if (p.ft.on) {
+      fin_store(&p.bias_part[((int64_t)n * p.chunks + chunk) * p.k + tid],
+                (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]));
+    {
       extern __shared__ double dice_tail_lds[];
-      fin_tail_run(p.ft, p.bias_part, dice_tail_lds, p.cfin);
+      fin_tail_run<ChanSumFin, 256, offsetof(DiceParams, ft), offsetof(DiceParams, cfin)>(p.bias_part, dice_tail_lds);
     }
   }
 }

@@ -267,11 +267,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
     const int g = ch / VEC, k = ch % VEC;
     float acc = 0.f;
     for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 3 * VEC + which * VEC + k];
-    p.out_partials[((int64_t)blockIdx.x * 3 + which) * p.c + ch] = acc;
+    fin_store(&p.out_partials[((int64_t)blockIdx.x * 3 + which) * p.c + ch], acc);
   }
-  if (p.ft.on) {
+  {
     extern __shared__ double fin_tail_lds_[];
-    fin_tail_run(p.ft, p.out_partials, fin_tail_lds_, p.bbfin);
+    fin_tail_run<BnBwdFin, 256, offsetof(EwParams, ft), offsetof(EwParams, bbfin)>(p.out_partials, fin_tail_lds_);
   }
 }
 

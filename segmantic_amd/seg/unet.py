@@ -619,6 +619,8 @@ class UNetEngine:
         # concurrently with the dgrad / BatchNorm-backward chain of the main stream (the
         # mid / deep levels do not fill 256 CUs with one kernel at a time).  All wgrads share the
         # side stream, hence also their scratch buffer, in issue order.
+        if self._diag_skip_wgrad:      # diagnostics only: time the main chain without its side-stream partner
+            return
         if self._defer_open:
             # issued later, when the main chain is down in the small deep levels (see defer_top_wgrad)
             self._deferred.append((conv, x, dy, need_bias, in_tf))
@@ -1135,6 +1137,7 @@ class UNetEngine:
     # per step with the buckets going through RCCL on one rank).  SEGMI_DEFER_TOP_WGRAD=0 issues every weight gradient as soon as its operands exist;
     # SEGMI_DEFER_DEPTH overrides the level at which the queue is flushed.
     defer_top_wgrad = os.environ.get("SEGMI_DEFER_TOP_WGRAD", "1") != "0"
+    _diag_skip_wgrad = os.environ.get("SEGMI_DIAG_SKIP_WGRAD") == "1"      # WRONG gradients: timing probes only
     _defer_depth_env = os.environ.get("SEGMI_DEFER_DEPTH")
 
     @property
