@@ -41,6 +41,12 @@ typedef struct segmi_act {
 
 int segmi_version(void);
 const char* segmi_last_error(void);
+/* A HIP stream restricted to `cus_enabled` compute units (a multiple of 8: the first cus_enabled / 8 CUs
+ * of every XCD; hipExtStreamCreateWithCUMask).  For the weight-gradient stream of a training step, which
+ * the reference leaves to autograd's single stream (monai_unet.py:345): the persistent weight-gradient
+ * kernels then cannot take every CU away from the dependent chain of the main stream. */
+int segmi_stream_create_cumask(int cus_enabled, void** stream_out);
+int segmi_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------- weights -------------- */
 /* Fragment-packed weights: the layout the MFMA kernels stream as B/A operands.

@@ -78,6 +78,8 @@ _d = C.c_double
 SIGNATURES = {
     "segmi_version": (_i, []),
     "segmi_last_error": (C.c_char_p, []),
+    "segmi_stream_create_cumask": (_i, [_i, C.POINTER(C.c_void_p)]),
+    "segmi_stream_destroy": (_i, [_P]),
     "segmi_wpack_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "segmi_wpack": (_i, [_i, _i, _P, _P, _i, _i, _i, _P, _P]),
     "segmi_wpack_batch": (_i, [_i, C.POINTER(WpackDesc), _i, _P, _i, _P]),

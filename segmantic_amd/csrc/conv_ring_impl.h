@@ -65,6 +65,11 @@ static inline int conv_ring_zsplit(int dtype, int cin, int ksize, int stride, in
                                    int Wo) {
   if (!(ksize == 3 && stride == 1 && cin == pick_ck(dtype, cin) && Wo > 8)) return 0;
   if (dtype != SEGMI_BF16) return 0;
+  // the kernel addresses one sample with 32-bit "plane index x plane size" products (bytes for the
+  // input, elements for the others); rows may be strided views (ld up to 4 x cin in this engine: skip
+  // buffers, padded class axis).  Larger samples take the tile / K-split kernels (64-bit addressing)
+  // -- every eligibility predicate (in_affine_ok, bn_bwd_sums_ok, stats_rows, kernel_name) follows.
+  if ((int64_t)(Do + 8) * Ho * Wo * (4 * cin) * 2 >= (1ll << 31)) return 0;
   const int columns = N * cdiv(Ho, 8) * cdiv(Wo, 16);
   const int steps = cdiv(Do, 4);
   int zs = 512 / columns;

@@ -366,6 +366,18 @@ static inline bool wgrad_ws_cfg_ok(int stride, int ct) {
   (void)stride;
   return ct == 11 || ct == 21;
 }
+// CUs the persistent weight-gradient kernels size their grids for (default: the whole chip).  With the
+// weight-gradient stream restricted to a CU mask (segmi_stream_create_cumask, SEGMI_SIDE_CUS) the grid
+// must match the mask or a second, ragged round of workgroups appears.
+static inline int wgrad_cus() {
+  static const int v = [] {
+    const char* e = getenv("SEGMI_WGRAD_CUS");
+    int n = e ? atoi(e) : 256;
+    n = n / 8 * 8;
+    return n < 8 ? 8 : (n > 256 ? 256 : n);
+  }();
+  return v;
+}
 static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride) {
   static const bool enabled = !(getenv("SEGMI_WGRAD_WS") && atoi(getenv("SEGMI_WGRAD_WS")) == 0);
   if (!enabled || dtype != SEGMI_BF16 || ksize != 3) return 0;
@@ -373,7 +385,7 @@ static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy
   if (!wgrad_ws_cfg_ok(stride, ct)) return 0;
   const int cto = ct / 10, cti = ct % 10;
   const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
-  int gx = 256 / chunks / 8 * 8;        // one 512-thread workgroup per CU, a multiple of the 8 XCDs
+  int gx = wgrad_cus() / chunks / 8 * 8;        // one 768-thread workgroup per CU, a multiple of the 8 XCDs
   if (gx < 8) return 0;
   // the tile shapes of launch_wgrad_ws (must match)
   const bool wide = dy->w > 8;
@@ -394,7 +406,7 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
   // workgroups wanted = a multiple of the 256 CUs; one per CU once the kernel holds > 1 channel
   // tile (200-400 VGPRs, 55-110 KB slabs).  Measured on MI355X: 1x1 blocks
   // 704/508/540/608 us at 256/512/1024/2048 workgroups, 2x2 blocks 125/198/348 us at 256/512/1024.
-  const int target = cto * cti == 1 ? 512 : 256;
+  const int target = cto * cti == 1 ? 2 * wgrad_cus() : wgrad_cus();
   int gx = target / chunks;
   if (gx < 1) gx = 1;
   const int nt = wgrad_tiles(dy, stride, cto * cti == 1);

@@ -165,6 +165,32 @@ extern "C" {
 int segmi_version(void) { return SEGMI_VERSION; }
 const char* segmi_last_error(void) { return g_err; }
 
+// A stream whose kernels run on a subset of the compute units.  MI355X: 256 CUs = 8 XCDs x 32; KFD
+// deals the bits of a CU mask round-robin over the XCDs (bit b -> XCD b % 8, local CU b / 8), so
+// enabling bits [0, 8 k) gives the first k CUs of EVERY XCD -- the remaining 32 - k per XCD stay free
+// for the other streams (which may still use all of them).
+int segmi_stream_create_cumask(int cus_enabled, void** stream_out) {
+  SEGMI_CHECK_ARG(stream_out && cus_enabled >= 8 && cus_enabled <= 256 && cus_enabled % 8 == 0,
+                  "stream_create_cumask: cus_enabled must be a multiple of 8 in [8, 256]");
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < cus_enabled; ++b) mask[b >> 5] |= 1u << (b & 31);
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, 8, mask);
+  if (e != hipSuccess) {
+    set_error("stream_create_cumask: %s", hipGetErrorString(e));
+    return SEGMI_ELAUNCH;
+  }
+  *stream_out = (void*)st;
+  return SEGMI_OK;
+}
+int segmi_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    set_error("stream_destroy failed");
+    return SEGMI_ELAUNCH;
+  }
+  return SEGMI_OK;
+}
+
 int64_t segmi_wpack_bytes(int dtype, int kind, int cin_k, int cout_k, int ksize) {
   if (cin_k % 16 || cout_k % 16 || cin_k <= 0 || cout_k <= 0) return 0;
   return wpack_elems(dtype, kind, cin_k, cout_k, ksize) * dtype_size(dtype);

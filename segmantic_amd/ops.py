@@ -156,6 +156,16 @@ def conv3d_bn_bwd_sums_ok(x, y, ksize, stride) -> bool:
     return bool(lib.segmi_conv3d_bn_bwd_sums_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
 
 
+def cu_masked_stream(cus_enabled: int, device=None) -> "torch.cuda.Stream":
+    """A torch stream over a HIP stream restricted to the first ``cus_enabled / 8`` CUs of every XCD
+    (segmi_stream_create_cumask).  The HIP stream lives as long as the process."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        check(lib.segmi_stream_create_cumask(int(cus_enabled), C.byref(h)), "stream_create_cumask")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def _bn_fin(fin):
     """fin = (count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift)
     -> byref(segmi_bn_fin) or None: the launch that writes the statistics rows also finalises them"""

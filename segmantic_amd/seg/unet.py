@@ -1109,9 +1109,16 @@ class UNetEngine:
     overlap_wgrad = os.environ.get("SEGMI_SERIAL", "0") != "1"
     _side = None
 
+    # SEGMI_SIDE_CUS=k: the weight-gradient stream may use only k CUs (k / 8 per XCD; a CU-masked HIP
+    # stream) -- set SEGMI_WGRAD_CUS to the same value so the persistent kernels size their grids for it
+    _side_cus = int(os.environ.get("SEGMI_SIDE_CUS", "0") or 0)
+
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            if self._side_cus:
+                self._side = ops.cu_masked_stream(self._side_cus, self.device)
+            else:
+                self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     # residual-branch overlap on a second side stream: measured neutral on MI355X (the branch

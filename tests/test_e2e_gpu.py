@@ -862,3 +862,33 @@ def test_convergence_matches_cpu_reference(golden_dir, record_property):
     print(f"convergence bf16: |val_dice - oracle| = {bd}, train-loss rel. {bt:.2e}")
     record_property("bf16_val_dice_dev", bd)
     assert max(bd) < 5e-2 and bt < 2e-2
+
+
+@pytest.mark.parametrize("size,batch", [(64, 2), (128, 1)])
+def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch):
+    """the default training path re-orders side-stream launches (weight gradients of the upper
+    decoder levels issued late, SEGMI_DEFER_TOP_WGRAD) and holds operand buffers across levels; the
+    finalisations run inside their producers (SEGMI_FUSE_FIN).  Neither may change a single bit of the
+    gradient arena or of the updated weights: immediate issue and every flush depth give the same."""
+    K = 16
+    img, lab = synthetic_batch(batch, size, K, seed=5)
+    batch_d = {"image": img.to(DEV), "label": lab.to(DEV)}
+
+    def run(defer, depth=None):
+        _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
+        net.mixed_precision = True
+        net.train()
+        eng = net._engine_for(batch_d["image"])
+        eng.defer_top_wgrad = defer
+        if depth is not None:
+            eng._defer_depth_env = str(depth)
+        for _ in range(2):
+            net.training_step(batch_d)
+        torch.cuda.synchronize()
+        return eng.flat_grad.clone(), eng.flat.clone()
+
+    g0, w0 = run(False)
+    for defer, depth in ((True, None), (True, 0), (True, 2)):
+        g, w = run(defer, depth)
+        assert torch.equal(g0, g), (defer, depth, float((g0 - g).abs().max()))
+        assert torch.equal(w0, w), (defer, depth)

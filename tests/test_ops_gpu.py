@@ -1159,6 +1159,8 @@ WS_WGRAD_CASES = [
     (16, 64, 3, 2, (63, 66, 126), 2),      # stride 2, two output-channel chunks (grid.y = 2), ragged
     (16, 16, 3, 2, (48, 80, 160), 2),      # stride 2, 16 x 16
     (16, 16, 3, 1, (40, 64, 8), 8),        # narrow volumes: the 8-wide tile, tap-split consumers
+    (32, 16, 3, 1, (18, 64, 128), 2),      # 32 input channels: X staged in two 16-channel chunks (ci0 = 0, 16)
+    (32, 16, 3, 2, (64, 64, 128), 2),      # the same with stride 2
 ]
 
 
@@ -1185,6 +1187,18 @@ def test_wave_specialised_wgrad_matches_torch(case):
     ops.conv3d_wgrad(wide[..., cin:], dyd, dw, None, k, s, ws)
     torch.cuda.synchronize()
     assert relerr(dw.cpu(), w0.grad) < 5e-5
+    # the fused input transform (segmi_in_affine) on the wave-specialised path: same bits as the
+    # weight gradient of the separately normalised tensor
+    scale = (rnd((cin,), 333).abs() + 0.5).to(DEV)
+    shift = (rnd((cin,), 334) * 0.3).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV)
+    xn = torch.empty_like(xd)
+    ops.bn_act_fwd(xd, xn, scale, shift, alpha)
+    dw_ref, dw_tf = torch.empty_like(dw), torch.empty_like(dw)
+    ops.conv3d_wgrad(xn, dyd, dw_ref, None, k, s, ws)
+    ops.conv3d_wgrad(xd, dyd, dw_tf, None, k, s, ws, in_tf=(scale, shift, alpha))
+    torch.cuda.synchronize()
+    assert torch.equal(dw_ref, dw_tf)
 
 
 # ------------------------------------------------------------------ finalisation inside the producing launch
@@ -1353,3 +1367,25 @@ def test_bn_backward_sums_finalised_by_the_input_gradient_launch():
     for a, g_, name in zip(ref, got, ("dgamma", "dbeta", "dalpha", "coef")):
         assert bool(torch.isfinite(g_).all()), name
         assert float((a - g_).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, name
+
+
+def test_ring_kernel_predicates_refuse_samples_beyond_its_32_bit_addressing():
+    """the z-marching ring kernel addresses one sample with 32-bit offsets; samples beyond
+    that must be routed to the 64-bit kernels by EVERY predicate (not fail in the launcher)."""
+    ok = torch.empty((1, 128, 128, 128, 16), dtype=torch.bfloat16, device=DEV)
+    assert ops.conv3d_in_affine_ok(ok, ok, 3, 1) and ops.conv3d_bn_bwd_sums_ok(ok, ok, 3, 1)
+    assert "ring2" in ops.conv3d_fwd_kernel_name(ok, ok, 3, 1)
+    big = torch.empty((1, 416, 416, 416, 16), dtype=torch.bfloat16, device=DEV)     # 2.3 GB, one sample
+    assert not ops.conv3d_in_affine_ok(big, big, 3, 1) and not ops.conv3d_bn_bwd_sums_ok(big, big, 3, 1)
+    assert "ring2" not in ops.conv3d_fwd_kernel_name(big, big, 3, 1)
+    # and the layer still runs (a thin slab of it: the tile kernel), with statistics rows that match its kernel
+    del big
+    x = to_ndhwc(rnd((1, 16, 4, 416, 416), 5), torch.bfloat16)
+    w = rnd((16, 16, 3, 3, 3), 6, 0.05)
+    y = torch.empty_like(x)
+    rows = ops.conv3d_stats_rows(x, y, 3, 1)
+    stats = torch.zeros((rows, 2, 16), device=DEV)
+    ops.conv3d_fwd(x, y, ops.wpack(torch.bfloat16, 0, w.to(DEV), 16, 16, 3), None, 0, None, 3, 1, stats=stats)
+    torch.cuda.synchronize()
+    ref = F.conv3d(from_ndhwc(x), q(w, torch.bfloat16), padding=1)
+    assert relerr(from_ndhwc(y), ref) < BF16_RTOL
