@@ -147,10 +147,20 @@ class Net(torch.nn.Module):
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        if self._engine is not None:
+            self._engine.sync_weights()
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._engine is not None:
             self._engine.bump()
         return out
+
+    def state_dict(self, *a, **k):
+        # parameters alias the engine's arena; the tail of the last training step (the carried layers'
+        # update) runs on the weight-gradient stream: the reader's stream waits for it first
+        if self._engine is not None:
+            with torch.cuda.device(self._engine.device):
+                self._engine.sync_weights()
+        return super().state_dict(*a, **k)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -220,12 +230,20 @@ class Net(torch.nn.Module):
                                     bias_grad=eng.top_bias_grad())
             if self._gsync is not None:
                 self._gsync.start()
-            eng.backward(dlogits, top_bias_done=True)
+            carried = eng.backward(dlogits, top_bias_done=True, carry=self._gsync is None)
             scale = 1.0
             if self._gsync is not None:
                 self._gsync.finish()
                 scale = self._gsync.grad_scale
-            opt.step(scale)
+            if carried:
+                # the weight gradients of the two full-resolution decoder convolutions are still running on
+                # the weight-gradient stream (they overlap the NEXT step's forward, UNetEngine.carry_top_wgrad):
+                # update the rest of the arena here, the suffix behind them on their stream
+                opt.step(scale, 0, eng.carry_lo)
+                eng.finish_carried(lambda: opt.step(scale, eng.carry_lo, None, advance=False),
+                                   eng.weights_version + 1)
+            else:
+                opt.step(scale)
             eng.bump()
         return {"loss": loss}
 

@@ -28,8 +28,18 @@ class FlatOptimizer:
     def state_dict(self):
         return {"lr": self.lr, "steps": self.steps}
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+        """One update of the arena range ``[lo, hi)`` (default: all of it).  A training step that updates
+        the arena in two pieces (``UNetEngine.finish_carried``) passes ``advance=False`` with the second
+        one: both pieces belong to the same step (bias corrections, SGD's first-step rule)."""
         raise NotImplementedError
+
+    def _range(self, lo, hi):
+        hi = self.flat.numel() if hi is None else int(hi)
+        lo = int(lo)
+        if not 0 <= lo <= hi <= self.flat.numel():
+            raise ValueError(f"optimizer range [{lo}, {hi}) outside the arena of {self.flat.numel()} parameters")
+        return lo, hi
 
 
 class FlatAdam(FlatOptimizer):
@@ -41,11 +51,14 @@ class FlatAdam(FlatOptimizer):
         self.exp_avg_sq = torch.zeros_like(flat)
         self.max_exp_avg_sq = torch.zeros_like(flat) if amsgrad else None
 
-    def step(self, grad_scale: float = 1.0):
-        self.steps += 1
-        ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq,
-                      self.max_exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.weight_decay, self.steps, grad_scale)
+    def step(self, grad_scale: float = 1.0, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+        lo, hi = self._range(lo, hi)
+        if advance:
+            self.steps += 1
+        if hi > lo:
+            ops.adam_step(self.flat[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                          None if self.max_exp_avg_sq is None else self.max_exp_avg_sq[lo:hi], self.lr,
+                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, grad_scale)
 
 
 class FlatSGD(FlatOptimizer):
@@ -54,10 +67,13 @@ class FlatSGD(FlatOptimizer):
         self.momentum, self.weight_decay = momentum, weight_decay
         self.buf = torch.zeros_like(flat) if momentum != 0 else None
 
-    def step(self, grad_scale: float = 1.0):
-        self.steps += 1
-        ops.sgd_step(self.flat, self.flat_grad, self.buf, self.lr, self.momentum,
-                     self.weight_decay, self.steps == 1, grad_scale)
+    def step(self, grad_scale: float = 1.0, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+        lo, hi = self._range(lo, hi)
+        if advance:
+            self.steps += 1
+        if hi > lo:
+            ops.sgd_step(self.flat[lo:hi], self.flat_grad[lo:hi], None if self.buf is None else self.buf[lo:hi],
+                         self.lr, self.momentum, self.weight_decay, self.steps == 1, grad_scale)
 
 
 class FlatAdaBelief(FlatOptimizer):
@@ -69,11 +85,14 @@ class FlatAdaBelief(FlatOptimizer):
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_var = torch.zeros_like(flat)
 
-    def step(self, grad_scale: float = 1.0):
-        self.steps += 1
-        ops.adabelief_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_var, self.lr,
-                           self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                           self.weight_decouple, self.steps, grad_scale)
+    def step(self, grad_scale: float = 1.0, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+        lo, hi = self._range(lo, hi)
+        if advance:
+            self.steps += 1
+        if hi > lo:
+            ops.adabelief_step(self.flat[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi],
+                               self.exp_avg_var[lo:hi], self.lr, self.betas[0], self.betas[1], self.eps,
+                               self.weight_decay, self.weight_decouple, self.steps, grad_scale)
 
 
 def make_optimizer(cfg: dict, flat, flat_grad) -> FlatOptimizer:

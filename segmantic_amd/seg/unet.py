@@ -178,6 +178,8 @@ class _Conv:
         if self.eng._packed_version != ver:
             self.eng._repack_all()
         self.eng._await_packs()
+        if self in self.eng._carry_convs:
+            self.eng.sync_weights()          # its update + re-pack of the last step ran on the side stream
         hit = self._packs.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -303,6 +305,7 @@ class UNetEngine:
         self._lane = 0
         self._saved: Dict[str, torch.Tensor] = {}
         self.timings: Dict[str, list] = {}
+        self._carry_convs: set = set()
         self.fixed_slope = torch.full((1,), FIXED_SLOPE.get(params.act, 0.0), dtype=torch.float32,
                                       device=self.device)
         self._build_arena()
@@ -411,21 +414,42 @@ class UNetEngine:
         every MFMA convolution for the current ``weights_version``."""
         ver = self.weights_version
         if self._wbatch is None:
-            entries, slots = [], []
+            groups = {False: ([], []), True: ([], [])}         # [carried?] -> (entries, slots)
             for conv in self._convs:
                 if not conv.mfma:
                     continue
+                entries, slots = groups[conv in self._carry_convs]
                 for tag, geom in (("fwd", conv.fwd_geom()), ("dgrad", conv.dgrad_geom())):
                     kind, cin_k, cout_k, k = geom
                     entries.append((kind, conv.w, None, cin_k, cout_k, k))
                     slots.append((conv, (tag, self.dtype)))
-            self._wbatch = (ops.WpackBatch(self.dtype, entries), slots) if entries else (None, [])
-        batch, slots = self._wbatch
+            self._wbatch = {c: ((ops.WpackBatch(self.dtype, e), sl) if e else (None, [])) for c, (e, sl) in groups.items()}
+        for carried in (False, True):
+            if carried and self._tail_packed_version == ver:
+                continue                   # done by the tail of the last training step (repack_tail)
+            if carried:
+                self.sync_weights()        # their optimiser update may have run on the weight-gradient stream
+            batch, slots = self._wbatch[carried]
+            if batch is not None:
+                batch.run()
+                for (conv, key), buf in zip(slots, batch.packed):
+                    conv._packs[key] = (ver, buf)
+        self._packed_version = ver
+
+    _tail_packed_version = -1
+
+    def repack_tail(self, ver: int):
+        """packs of the carried convolutions for weights version ``ver`` (current stream = the
+        weight-gradient stream, right after their optimiser update)"""
+        if self._wbatch is None:
+            self._packed_version = -1          # first step: the table does not exist yet -> full re-pack later
+            return
+        batch, slots = self._wbatch[True]
         if batch is not None:
             batch.run()
             for (conv, key), buf in zip(slots, batch.packed):
                 conv._packs[key] = (ver, buf)
-        self._packed_version = ver
+        self._tail_packed_version = ver
 
     _pack_ev = None
 
@@ -434,7 +458,9 @@ class UNetEngine:
         main stream does the first layer (Cin = 1: no packed operand); the first MFMA conv waits."""
         if self._packed_version == self.weights_version or not self.overlap_wgrad:
             return
-        main, side = torch.cuda.current_stream(), self._side_stream()
+        # (with carried weight gradients the weight-gradient stream is still busy with the last step's
+        # tail: the re-pack of all other layers takes a stream of its own)
+        main, side = torch.cuda.current_stream(), (self._pack_stream() if self._tail_ev is not None else self._side_stream())
         ev = torch.cuda.Event()
         ev.record(main)                 # after the optimiser step that changed the weights
         side.wait_event(ev)
@@ -461,6 +487,13 @@ class UNetEngine:
     def _build_plan(self):
         chs, sts = list(self.net.channels), list(self.net.strides)
         self.levels = self._make_level("", self.net.in_channels, self.kpad, chs, sts, True)
+        # carried weight gradients (see carry_top_wgrad): the two full-resolution decoder convolutions;
+        # their parameters (with the BatchNorm between them) are the contiguous END of the arena
+        top = self.levels
+        self._carry_convs = {top["upconv"]} | {c for c, _ in top["upru"]["units"]}
+        self.carry_lo = self.param_offsets["model.2.0.conv.weight"][0]
+        assert all(off >= self.carry_lo for name, (off, _n) in self.param_offsets.items() if name.startswith("model.2.")) \
+            and all(off < self.carry_lo for name, (off, _n) in self.param_offsets.items() if not name.startswith("model.2."))
 
     def _make_ru(self, prefix, cin, cout, stride, subunits, last_conv_only=False):
         units = []
@@ -620,6 +653,9 @@ class UNetEngine:
         # mid / deep levels do not fill 256 CUs with one kernel at a time).  All wgrads share the
         # side stream, hence also their scratch buffer, in issue order.
         if self._diag_skip_wgrad:      # diagnostics only: time the main chain without its side-stream partner
+            return
+        if self._carry_open and conv in self._carry_convs:
+            self._carried.append((conv, x, dy, need_bias, in_tf))     # issued after the end of backward
             return
         if self._defer_open:
             # issued later, when the main chain is down in the small deep levels (see defer_top_wgrad)
@@ -890,6 +926,10 @@ class UNetEngine:
         n, d, h, w = self._down_shape(x.shape, lvl["stride"])
         c, upc, subc = lvl["c"], lvl["upc"], lvl["subc"]
         tag = "t" if train else "e"
+        if train and lvl["is_top"] and self.carry_top_wgrad and self.grad_hook is None and self.overlap_wgrad:
+            # the carried transposed-conv weight gradient of the LAST step may still be reading the last
+            # step's skip buffer: alternate between two
+            tag = "t" + str(self._fwd_parity)
         cat = self._buf(f"{p}cat.{tag}", (n, d, h, w, upc))
         down_out = cat[..., :c]
         sub_out = cat[..., c:]
@@ -902,6 +942,8 @@ class UNetEngine:
         up, ubn = lvl["upconv"], lvl["upbn"]
         oshape = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], lvl["outc"])
         if train:
+            if lvl["is_top"]:
+                self.sync_weights()        # parameters of the carried layers, and their readers of u / scale / shift
             u = self._buf(f"{p}u", oshape)
             self._conv_train(up, cat, u, ubn)
             upru = lvl["upru"]
@@ -1018,7 +1060,11 @@ class UNetEngine:
         finally:
             self._lane = 0
 
+    _fwd_parity = 0
+
     def _forward(self, x, train, out):
+        if not train:
+            self.sync_weights()
         xin = self._prep_input(x)
         n, d, h, w, _ = xin.shape
         k = self.net.out_channels
@@ -1034,6 +1080,7 @@ class UNetEngine:
         else:
             logits = self._buf("logits." + ("t" if train else "e"), shape)
         if train:
+            self._fwd_parity ^= 1
             self._repack_async()
             self._saved.clear()
             self._nbt_flat += 1        # every BatchNorm runs exactly once per training forward
@@ -1056,8 +1103,14 @@ class UNetEngine:
         that already walks dlogits can fill it (``backward(..., top_bias_done=True)``)."""
         return self.levels["upru"]["units"][-1][0].gb
 
-    def backward(self, dlogits: torch.Tensor, top_bias_done: bool = False) -> None:
-        """dlogits NDHWC (compute dtype).  Fills the flat gradient arena (overwrites)."""
+    def backward(self, dlogits: torch.Tensor, top_bias_done: bool = False, carry: bool = False) -> bool:
+        """dlogits NDHWC (compute dtype).  Fills the flat gradient arena (overwrites).
+
+        ``carry`` (``Net.training_step`` only): the weight gradients of the two full-resolution decoder
+        convolutions are issued on the weight-gradient stream AFTER the main stream has joined it, i.e.
+        they are not part of what the caller's stream waits for: the caller must finish the step with
+        ``finish_carried()`` (optimiser update of the arena suffix ``[carry_lo, n)`` + re-pack on that
+        stream) and update only ``[0, carry_lo)`` itself.  Returns True when that is the case."""
         if not self._saved:
             raise RuntimeError("backward() needs a preceding training-mode forward()")
         self._top_bias_conv = self.levels["upru"]["units"][-1][0] if top_bias_done else None
@@ -1072,6 +1125,9 @@ class UNetEngine:
             dlogits = full
         self._deferred = []
         self._defer_open = self.defer_top_wgrad and self.grad_hook is None and self.overlap_wgrad
+        self._carried = []
+        self._carry_open = (carry and self.carry_top_wgrad and self.grad_hook is None and self.overlap_wgrad
+                            and not self._diag_skip_wgrad)
         self._bwd_depth = 0
         try:
             self._level_bwd(self.levels, dlogits)
@@ -1079,8 +1135,54 @@ class UNetEngine:
                 self._flush_deferred()
         finally:
             self._defer_open = False
+            carried, self._carry_open = self._carry_open, False
         self._top_bias_conv = None
         self._join_side()
+        if carried:
+            # behind the join: nothing on the caller's stream waits for these
+            todo, self._carried = self._carried, []
+            for conv, x, dy, need_bias, in_tf in todo:
+                self._wgrad(conv, x, dy, need_bias=need_bias, in_tf=in_tf)
+        return carried
+
+    # Single-GPU training_step: the weight gradients of the two full-resolution decoder convolutions
+    # (0.73 ms of HBM-bound persistent kernels, 1.6 GB) are carried over the end of the step: beside the
+    # backward's own bandwidth-bound kernels they only stretch it (backward 2.30 ms alone, 3.79 ms with
+    # all weight gradients beside it, 4.13 ms serial: the overlap buys 0.34 ms), beside the NEXT step's
+    # forward -- whose 64^3 .. 8^3 levels are latency-bound and leave the memory system idle -- they are
+    # nearly free.  Their layers are the last ones a forward reaches, so there is ~1 ms of slack: the
+    # weight-gradient stream runs them, then the optimiser on the arena suffix [carry_lo, n) and the
+    # re-pack of the two layers, and records `_tail_ev`; the next forward waits for it in front of the
+    # top transposed convolution.  Same arithmetic in the same order per parameter: bit-identical weights
+    # (tests/test_e2e_gpu.py).  SEGMI_CARRY_TOP_WGRAD=0: everything inside the step, as before.
+    carry_top_wgrad = os.environ.get("SEGMI_CARRY_TOP_WGRAD", "1") != "0"
+    _carry_open = False
+    _carried: list = []
+    _tail_ev = None
+    _packs_stream = None
+
+    def _pack_stream(self):
+        if self._packs_stream is None:
+            self._packs_stream = torch.cuda.Stream(device=self.device)
+        return self._packs_stream
+
+    def finish_carried(self, update_suffix, new_version: int):
+        """``update_suffix()``: the optimiser kernel over ``[carry_lo, n)``.  Runs it and the re-pack of the
+        carried layers on the weight-gradient stream behind their weight gradients."""
+        main, side = torch.cuda.current_stream(), self._side_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)              # the suffix's BatchNorm / bias gradients come from the main chain
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            update_suffix()
+            self.repack_tail(new_version)
+            self._tail_ev = torch.cuda.Event()
+            self._tail_ev.record(side)
+
+    def sync_weights(self):
+        """the current stream waits until every parameter (and pack) of the last training step is final"""
+        if self._tail_ev is not None:
+            torch.cuda.current_stream().wait_event(self._tail_ev)
 
     _top_bias_conv = None
 

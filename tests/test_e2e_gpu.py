@@ -867,28 +867,40 @@ def test_convergence_matches_cpu_reference(golden_dir, record_property):
 @pytest.mark.parametrize("size,batch", [(64, 2), (128, 1)])
 def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch):
     """the default training path re-orders side-stream launches (weight gradients of the upper
-    decoder levels issued late, SEGMI_DEFER_TOP_WGRAD) and holds operand buffers across levels; the
-    finalisations run inside their producers (SEGMI_FUSE_FIN).  Neither may change a single bit of the
-    gradient arena or of the updated weights: immediate issue and every flush depth give the same."""
+    decoder levels issued late, SEGMI_DEFER_TOP_WGRAD) and holds operand buffers across levels; round 3
+    carries the weight gradients of the two full-resolution decoder convolutions (and the optimiser update
+    + re-pack of those layers) over the END of the step, beside the next forward.  None of it may change a
+    single bit of the gradient arena, of the updated weights, of a checkpoint taken right after a step or
+    of an eval forward: immediate issue, every flush depth and carry on / off give the same."""
     K = 16
     img, lab = synthetic_batch(batch, size, K, seed=5)
     batch_d = {"image": img.to(DEV), "label": lab.to(DEV)}
 
-    def run(defer, depth=None):
+    def run(defer, depth=None, carry=False, steps=3):
         _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
         net.mixed_precision = True
         net.train()
         eng = net._engine_for(batch_d["image"])
         eng.defer_top_wgrad = defer
+        eng.carry_top_wgrad = carry
         if depth is not None:
             eng._defer_depth_env = str(depth)
-        for _ in range(2):
+        for _ in range(steps):
             net.training_step(batch_d)
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}    # reader of the arena: syncs by itself
         torch.cuda.synchronize()
-        return eng.flat_grad.clone(), eng.flat.clone()
+        # an eval forward right after training sees the final weights of the carried layers
+        net.eval()
+        with torch.no_grad():
+            y = net(batch_d["image"]).float().cpu()
+        return eng.flat_grad.clone(), eng.flat.clone(), sd, y
 
-    g0, w0 = run(False)
-    for defer, depth in ((True, None), (True, 0), (True, 2)):
-        g, w = run(defer, depth)
-        assert torch.equal(g0, g), (defer, depth, float((g0 - g).abs().max()))
-        assert torch.equal(w0, w), (defer, depth)
+    g0, w0, sd0, y0 = run(False)
+    # (defer, flush depth, weight gradients of the full-resolution decoder carried into the next step)
+    for defer, depth, carry in ((True, None, False), (True, 0, False), (True, 2, False), (True, None, True),
+                                (False, None, True)):
+        g, w, sd, y = run(defer, depth, carry)
+        assert torch.equal(g0, g), (defer, depth, carry, float((g0 - g).abs().max()))
+        assert torch.equal(w0, w), (defer, depth, carry)
+        assert all(torch.equal(sd0[k], sd[k]) for k in sd0), (defer, depth, carry)
+        assert torch.equal(y0, y), (defer, depth, carry)
