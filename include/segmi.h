@@ -170,8 +170,9 @@ int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
  * segmi_dectop_ok(): bf16, in [N,D,H,W,32], out [N,2D,2H,2W,16] with 2D % 4 == 0, 2H % 16 == 0, 2W % 16 == 0. */
 int segmi_dectop_ok(int dtype, const segmi_act* in, const segmi_act* out);
 int segmi_dectop_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* up_frag,
-                     const float* up_bias, const float* up_alpha, const void* conv_packed,
-                     const float* conv_bias, void* stream);
+                     const float* up_bias, const float* up_alpha,
+                     int up_alpha_in_unit_range /* caller asserts 0 <= *up_alpha <= 1: PReLU as max(v, slope v), same bits */,
+                     const void* conv_packed, const float* conv_bias, void* stream);
 /* The first ResidualUnit of the network convolves its (<= 4 channel) input twice with the same
  * geometry: subunit 0 (k3, stride s) and the residual convolution (k3, stride s).  One launch
  * stages the input once and produces both:  out_a = prelu_a(conv_a(in) + bias_a) with optional

@@ -25,7 +25,7 @@ def two():
     ops.conv3d_fwd(h, out, cv_pack, None, 0, cb, 3, 1, residual=h)
 
 def one():
-    ops.dectop_fwd(x, out, frag, ub, alpha, cv_pack, cb)
+    ops.dectop_fwd(x, out, frag, ub, alpha, cv_pack, cb, alpha_in_unit_range=True)
 
 import os
 only = os.environ.get("SEGMI_DECTOP_DBG")

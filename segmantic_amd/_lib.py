@@ -92,7 +92,7 @@ SIGNATURES = {
                               C.POINTER(BnBwdSums), C.POINTER(BnFin), _P]),
     "segmi_conv3d_bn_bwd_sums_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_dectop_ok": (_i, [_i, _AP, _AP]),
-    "segmi_dectop_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P]),
+    "segmi_dectop_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _P, _P, _P]),
     "segmi_conv3d_pair_ok": (_i, [_i, _AP, _AP, _AP]),
     "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, C.POINTER(BnFin), _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),

@@ -31,6 +31,7 @@
 // loop is conv_ring2_kernel's: the result is bit-identical to the two-launch path.
 #include <type_traits>
 #include "conv_ring_impl.h"
+#include "convt_ps_impl.h"
 
 namespace segmi {
 
@@ -44,36 +45,42 @@ struct DecTopParams {
   const float* cv_bias;
   int N, Dc, Hc, Wc, Do, Ho, Wo, ldi, ldo;
   int ty, tx, tz;
-  int dbg;   // diag build only (SEGMI_DECTOP_DBG): 1 = no producer MFMAs, 2 = no conv loop, 4 = no output stores, 8 = no coarse loads
+  int dbg;   // SEGMI_DECTOP_DBG, timing probes: 1 = producers idle, 2 = consumers idle (wrong output)
+  int alpha01;   // the caller asserts 0 <= *up_alpha <= 1: PReLU as max(v, slope v)
 };
 
-#ifdef SEGMI_RING2_DIAG
-#define DT_DBG(p, bit) (((p).dbg & (bit)) != 0)
-#else
-#define DT_DBG(p, bit) false
-#endif
-
 namespace dectop {
-constexpr int TD = 4, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, R = 10;
-constexpr int ROWB = 32, PLANE_B = HH * HW * ROWB, RING_B = R * PLANE_B;           // 103,680
-constexpr int CR = 3, CH = TH / 2 + 2, CW = TW / 2 + 2, CROWB = 64;
-constexpr int CPLANE_B = CH * CW * CROWB, CAT_B = CR * CPLANE_B + 640;              // + overrun of lanes 10..15
-constexpr int WUP_B = 27 * 1024;
-constexpr int OFF_CAT = RING_B, OFF_WUP = OFF_CAT + CAT_B;
-constexpr int LDS_BYTES = OFF_WUP + WUP_B;                                          // 151,168
-constexpr int J = 5, NIT = 6 * J, PD = 2;
+constexpr int TD = 4, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2;
+constexpr int R = 11;                       // fine ring: 6 planes read + 1 held + 4 written per step
+constexpr int ROWB = 32, PLANE_B = HH * HW * ROWB, RING_B = R * PLANE_B;           // 114,048
+constexpr int CR = 3, CH = TH / 2 + 2, CW = TW / 2 + 2, CROWB = 64;                 // coarse ring: 3 planes of 10 x 10 voxels
+constexpr int CPLANE_B = CH * CW * CROWB;
+constexpr int CAT_B = CR * CPLANE_B + 1536;    // + overrun: idle lanes (base index up to 111) and the (+1, +1) neighbour reads
+constexpr int OFF_CAT = RING_B, OFF_DUMP = OFF_CAT + CAT_B;
+constexpr int LDS_BYTES = OFF_DUMP + 16;                                            // 133,968
+constexpr int J = 5, NIT = 6 * J, PD = 4;
 constexpr int NRO = 4;                      // output rows per consumer wave
-constexpr int NLP = 4;                      // chunks per producer thread of a 2-plane coarse stage (800 / 256)
-constexpr int NLC = 3;                      // 16-byte chunks per thread of a 3-plane coarse stage (1200 / 512)
+constexpr int NLP = 4;                      // 16-byte chunks per producer thread of a 2-plane coarse stage (800 / 256)
 constexpr int PLC = CH * CW * 4;            // chunks per coarse plane
+constexpr int NBASE = CH * CW;              // base voxels per coarse plane
+constexpr int NTILE = (NBASE + 15) / 16;    // 16-voxel tiles per coarse plane (7; 12 idle lanes in the last)
 }  // namespace dectop
 
+// Round 3: the producers are re-tiled the way convt_ps_kernel works.  A producer tile is 16 BASE voxels of
+// one coarse plane (the 10 x 10 coarse footprint of the column enumerated linearly: 7 tiles per plane, 100 of
+// 112 lanes busy instead of 9 of 16), and for a tile the wave computes ALL 8 output-parity classes from 8
+// neighbour fragments: 27 MFMAs per 8 emits, the 27 weight fragments of the transposed convolution in 108
+// VGPRs for the whole launch (they were re-read from LDS per plane: 380 KB of LDS reads per step on top
+// of the convolution's 480 KB).  A step produces the 4 fine planes of 2 coarse base planes, so the new
+// planes are 2c .. 2c + 3: the fine ring holds one plane more (11) and runs one plane ahead of round 2's.
+// Per step and producer wave: ~95 MFMAs, 28 neighbour reads, 28 emits of ~20 instructions (was: 121 MFMAs,
+// ~100 reads, 36 emits inside ~2000 instructions).
+template <bool A01>
 __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
   using namespace dectop;
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const catl = smem + OFF_CAT;
-  char* const wupl = smem + OFF_WUP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -90,10 +97,176 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
   const int z0 = seg * seg_steps * TD;
   const int nsteps_z = total_steps - seg * seg_steps < seg_steps ? total_steps - seg * seg_steps : seg_steps;
   if (nsteps_z <= 0) return;                 // workgroup-uniform
+  const int cz0 = z0 >> 1;
+  // fine plane f lives in ring slot (f - z0 + 2) % R, coarse plane c in slot c mod CR
+  auto ws_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  // ---- transposed-conv weights -> LDS
-  for (int i = tid; i < WUP_B / 16; i += 512)
-    reinterpret_cast<frag_t*>(wupl)[i] = reinterpret_cast<const frag_t*>(p.up_frag)[i];
+  if (wave >= 4) {
+    // =================================================================== producers
+    const int pw = wave - 4, ptid = tid & 255;
+    // ---- transposed-conv weights -> registers: A fragment of tap (kd, kh, kw)
+    frag_t Af[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) Af[k] = *reinterpret_cast<const frag_t*>((const char*)p.up_frag + k * 1024 + lane * 16);
+    f32x4 ubias = *reinterpret_cast<const f32x4*>(p.up_bias + 4 * g);
+    float ualpha = *p.up_alpha;
+    touch_v(ubias);
+    touch_s(ualpha);
+
+    // ---- coarse staging (256 threads, <= 2 planes per stage): slot k = chunk ptid + 256 k
+    const char* inb = (const char*)p.in;
+    const int64_t cplane_stride = (int64_t)p.Hc * p.Wc * p.ldi * 2;
+    const char* img = inb + (int64_t)n * p.Dc * cplane_stride;
+    int d_pl[NLP], d_goff[NLP], d_loff[NLP];
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int i = ptid + 256 * k;
+      const int pl = i / PLC, idx = i % PLC;
+      const int vox = idx >> 2, ch = idx & 3;
+      const int lr = vox / CW, lc = vox % CW;
+      const int cy = Y0 - 1 + lr, cx = X0 - 1 + lc;
+      const bool ok = (unsigned)cy < (unsigned)p.Hc && (unsigned)cx < (unsigned)p.Wc;
+      d_pl[k] = pl < 2 ? pl : -1;
+      d_goff[k] = ok ? (cy * p.Wc + cx) * p.ldi * 2 + ch * 16 : -1;
+      d_loff[k] = (lr * CW + lc) * CROWB + ch * 16;
+    }
+    frag_t dreg[NLP];
+    auto cat_fetch = [&](int c_first, int nplanes) {          // coarse planes c_first .. -> registers
+#pragma unroll
+      for (int k = 0; k < NLP; ++k) {
+        dreg[k] = frag_t{0u, 0u, 0u, 0u};
+        const int cz = c_first + d_pl[k];
+        if (d_pl[k] >= 0 && d_pl[k] < nplanes && (unsigned)cz < (unsigned)p.Dc && d_goff[k] >= 0)
+          dreg[k] = *reinterpret_cast<const frag_t*>(img + (int64_t)cz * cplane_stride + (unsigned)d_goff[k]);
+      }
+    };
+    auto cat_commit = [&](int c_first, int nplanes) {         // ... -> their ring slots (zeros outside the volume)
+#pragma unroll
+      for (int k = 0; k < NLP; ++k) {
+        if (d_pl[k] >= 0 && d_pl[k] < nplanes) {
+          const int cz = c_first + d_pl[k];
+          const int slot = ((cz % CR) + CR) % CR;
+          *reinterpret_cast<frag_t*>(catl + slot * CPLANE_B + d_loff[k]) = dreg[k];
+        }
+      }
+    };
+
+    // ---- per-lane geometry of the wave's tiles, computed once: a production round is 2 planes x 7 tiles
+    // dealt to the 4 producer waves (wave pw: i = pw, pw + 4, pw + 8, pw + 12 < 14; plane i / 7, tile i % 7),
+    // so slot q of the wave always holds the same 16 base voxels of the coarse footprint.
+    constexpr int NSL = 4;
+    int t_baddr[NSL], t_waddr[NSL];
+    unsigned t_mask[NSL];           // bits 0-3: write enable of (py, px) = inside the footprint; bits 4-7: inside the volume
+#pragma unroll
+    for (int q = 0; q < NSL; ++q) {
+      const int i = pw + 4 * q, k = i % NTILE;
+      const int v = 16 * k + r;
+      const bool lane_ok = v < NBASE && i < 2 * NTILE;
+      const int cyl = v / CW, cxl = v - cyl * CW;
+      const int jy0 = 2 * cyl - 1, jx0 = 2 * cxl - 1;          // footprint row / column of the even-parity output
+      t_baddr[q] = v * CROWB + g * 16;                          // the base voxel's channel chunk g in a coarse plane
+      t_waddr[q] = (jy0 * HW + jx0) * ROWB + 8 * g;             // its even-parity output voxel in a ring plane
+      unsigned m = 0;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int jy = jy0 + py, jx = jx0 + px;
+          if (lane_ok && (unsigned)jy < (unsigned)HH && (unsigned)jx < (unsigned)HW) m |= 1u << (py * 2 + px);
+          if ((unsigned)(oy0 - 1 + jy) < (unsigned)p.Ho && (unsigned)(ox0 - 1 + jx) < (unsigned)p.Wo) m |= 16u << (py * 2 + px);
+        }
+      t_mask[q] = m;
+    }
+    // ---- one tile: its 16 base voxels of a coarse plane -> the 8 fine voxels of each.  slotA / slotB: LDS
+    // offsets of that coarse plane and the next; pl0 / pl1: ring offsets of the fine planes 2 cb, 2 cb + 1;
+    // zin0 / zin1: those planes lie inside the volume (else zeros) -- all wave-uniform
+    auto produce_tile = [&](int q, int slotA, int slotB, int pl0, int pl1, bool zin0, bool zin1) {
+      const int baddr = t_baddr[q];
+      frag_t Bf[8];                                             // neighbour (dz, dy, dx) = bits of the index
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        Bf[o] = *reinterpret_cast<const frag_t*>(catl + ((o & 4) ? slotB : slotA) + baddr +
+                                                 (((o >> 1) & 1) * CW + (o & 1)) * CROWB);
+      // 27 MFMAs into 8 accumulators, round-robin over the classes (tap qq of every class that has one):
+      // within a class the taps keep convt_ps_kernel's order (x fastest; odd parity = (k = 2, this voxel)
+      // then (k = 0, next voxel)), so the sums are its bits
+      f32x4 acc[8];
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq)
+#pragma unroll
+        for (int cls = 0; cls < 8; ++cls) {
+          if (qq < ct_ntaps_c(cls)) {
+            const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+            const int nw = 1 + px, nh = 1 + py;
+            const int tw = qq % nw, th = (qq / nw) % nh, td = qq / (nw * nh);
+            const int kw = px ? (tw ? 0 : 2) : 1, kh = py ? (th ? 0 : 2) : 1, kd = pz ? (td ? 0 : 2) : 1;
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[cls] = mma16<T>(Af[(kd * 3 + kh) * 3 + kw], Bf[ctps_tap_a(cls, qq)], qq == 0 ? zero : acc[cls]);
+          }
+        }
+      const unsigned m = t_mask[q];
+      const int waddr = t_waddr[q];
+#pragma unroll
+      for (int cls = 0; cls < 8; ++cls) {
+        const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+        f32x4 vv = acc[cls] + ubias;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // A01 (0 <= slope <= 1, every PReLU in practice): max(v, slope v) == the select form bit for bit
+          if constexpr (A01) vv[e] = fmaxf(vv[e], ualpha * vv[e]);
+          else vv[e] = vv[e] > 0.f ? vv[e] : ualpha * vv[e];
+        }
+        const bool keep = (pz ? zin1 : zin0) && (m & (16u << (py * 2 + px))) != 0;
+        u32x2 o;
+        o[0] = keep ? pack_bf16x2(vv[0], vv[1]) : 0u;
+        o[1] = keep ? pack_bf16x2(vv[2], vv[3]) : 0u;
+        const bool wr = (m & (1u << (py * 2 + px))) != 0;
+        const int dst = wr ? (pz ? pl1 : pl0) + waddr + (py * HW + px) * ROWB : OFF_DUMP;
+        *reinterpret_cast<u32x2*>(smem + dst) = o;
+      }
+    };
+
+    // ---- rounds.  Round rr produces the base planes cb = cz0 - 1 + 2 rr, cb + 1 (fine planes 2 cb .. 2 cb + 3)
+    // from the coarse planes cb .. cb + 2, of which cb + 1, cb + 2 are new.  Rounds 0, 1 are the prologue
+    // (fine planes z0-2 .. z0+5), round s + 2 runs beside the convolution of step s; every round is
+    //   commit the new coarse planes | barrier X | fetch the next round's | produce | barrier Y
+    // and the last step has no round beside it (barriers only).
+    cat_fetch(cz0 - 1, 1);
+    cat_commit(cz0 - 1, 1);
+    cat_fetch(cz0, 2);
+    for (int rr = 0; rr <= nsteps_z + 1; ++rr) {
+      const bool work = rr <= nsteps_z;
+      const int cb0 = cz0 - 1 + 2 * rr;
+      if (work) cat_commit(cb0 + 1, 2);
+      ws_barrier();                                  // X: the coarse planes are in LDS
+      if (work && !(p.dbg & 1)) {
+        if (rr + 1 <= nsteps_z) cat_fetch(cb0 + 3, 2);
+        int cslot[3], pl[4];
+        bool zin[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cslot[c] = ((((cb0 + c) % CR) + CR) % CR) * CPLANE_B;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int fz = 2 * cb0 + f;                  // >= z0 - 2 always
+          pl[f] = ((fz - z0 + 2) % R) * PLANE_B;
+          zin[f] = (unsigned)fz < (unsigned)p.Do;
+        }
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) {
+          const int i = pw + 4 * q;                    // wave-uniform: plane i / 7 of the round, tile i % 7
+          if (i < 2 * NTILE) {
+            const bool hi = i >= NTILE;
+            produce_tile(q, hi ? cslot[1] : cslot[0], hi ? cslot[2] : cslot[1], hi ? pl[2] : pl[0],
+                         hi ? pl[3] : pl[1], hi ? zin[2] : zin[0], hi ? zin[3] : zin[1]);
+          }
+        }
+      }
+      ws_barrier();                                  // Y: the round's ring planes are complete, the step beside it consumed
+    }
+    return;
+  }
+
+  // ===================================================================== consumers: convolution of step s
   // ---- conv weights -> registers (two taps per k-step, gathered from the standard pack; ring2's layout)
   frag_t wreg[3][J];
 #pragma unroll
@@ -115,225 +288,7 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
     if (t9 > 8) t9 = 8;
     laneoff[j] = ((t9 / 3) * HW + t9 % 3 + r) * ROWB + (g & 1) * 16;
   }
-  const int wrow = (wave & 3) * NRO * HW * ROWB;   // consumer wave w: output rows 4w .. 4w+3 (footprint row 4w + kh)
-
-  // ---- coarse staging descriptors (slot k: chunk tid + 512 k of a <= 3-plane stage)
-  const char* inb = (const char*)p.in;
-  const int64_t cplane_stride = (int64_t)p.Hc * p.Wc * p.ldi * 2;
-  const char* img = inb + (int64_t)n * p.Dc * cplane_stride;
-  int c_pl[NLC], c_goff[NLC], c_loff[NLC];
-#pragma unroll
-  for (int k = 0; k < NLC; ++k) {
-    const int i = tid + 512 * k;
-    const int pl = i / PLC, idx = i % PLC;
-    const int vox = idx >> 2, ch = idx & 3;
-    const int lr = vox / CW, lc = vox % CW;
-    const int cy = Y0 - 1 + lr, cx = X0 - 1 + lc;
-    const bool ok = (unsigned)cy < (unsigned)p.Hc && (unsigned)cx < (unsigned)p.Wc;
-    c_pl[k] = pl < CR ? pl : -1;
-    c_goff[k] = ok ? (cy * p.Wc + cx) * p.ldi * 2 + ch * 16 : -1;
-    c_loff[k] = (lr * CW + lc) * CROWB + ch * 16;
-  }
-  frag_t creg[NLC];
-  auto cat_fetch = [&](int c_first, int nplanes) {      // coarse planes c_first .. c_first + nplanes - 1 -> registers
-#pragma unroll
-    for (int k = 0; k < NLC; ++k) {
-      creg[k] = frag_t{0u, 0u, 0u, 0u};
-      const int cz = c_first + c_pl[k];
-      if (c_pl[k] >= 0 && c_pl[k] < nplanes && (unsigned)cz < (unsigned)p.Dc && c_goff[k] >= 0 && !DT_DBG(p, 8))
-        creg[k] = *reinterpret_cast<const frag_t*>(img + (int64_t)cz * cplane_stride + (unsigned)c_goff[k]);
-    }
-  };
-  auto cat_commit = [&](int c_first, int nplanes) {     // ... -> their ring slots (zeros outside the volume)
-#pragma unroll
-    for (int k = 0; k < NLC; ++k) {
-      if (c_pl[k] >= 0 && c_pl[k] < nplanes) {
-        const int cz = c_first + c_pl[k];
-        const int slot = ((cz % CR) + CR) % CR;
-        *reinterpret_cast<frag_t*>(catl + slot * CPLANE_B + c_loff[k]) = creg[k];
-      }
-    }
-  };
-
-  // the same for the producers alone in the steady state: 2 new planes, 256 threads
-  const int ptid = tid & 255;
-  int d_pl[NLP], d_goff[NLP], d_loff[NLP];
-#pragma unroll
-  for (int k = 0; k < NLP; ++k) {
-    const int i = ptid + 256 * k;
-    const int pl = i / PLC, idx = i % PLC;
-    const int vox = idx >> 2, ch = idx & 3;
-    const int lr = vox / CW, lc = vox % CW;
-    const int cy = Y0 - 1 + lr, cx = X0 - 1 + lc;
-    const bool ok = (unsigned)cy < (unsigned)p.Hc && (unsigned)cx < (unsigned)p.Wc;
-    d_pl[k] = pl < 2 ? pl : -1;
-    d_goff[k] = ok ? (cy * p.Wc + cx) * p.ldi * 2 + ch * 16 : -1;
-    d_loff[k] = (lr * CW + lc) * CROWB + ch * 16;
-  }
-  frag_t dreg[NLP];
-  auto cat_fetch2 = [&](int c_first) {
-#pragma unroll
-    for (int k = 0; k < NLP; ++k) {
-      dreg[k] = frag_t{0u, 0u, 0u, 0u};
-      const int cz = c_first + d_pl[k];
-      if (d_pl[k] >= 0 && (unsigned)cz < (unsigned)p.Dc && d_goff[k] >= 0 && !DT_DBG(p, 8))
-        dreg[k] = *reinterpret_cast<const frag_t*>(img + (int64_t)cz * cplane_stride + (unsigned)d_goff[k]);
-    }
-  };
-  auto cat_commit2 = [&](int c_first) {
-#pragma unroll
-    for (int k = 0; k < NLP; ++k) {
-      if (d_pl[k] >= 0) {
-        const int cz = c_first + d_pl[k];
-        const int slot = ((cz % CR) + CR) % CR;
-        *reinterpret_cast<frag_t*>(catl + slot * CPLANE_B + d_loff[k]) = dreg[k];
-      }
-    }
-  };
-
-  // ---- producer of the ring planes: h = PReLU(convT(x) + bias) over the footprint, zero outside the volume
-  f32x4 ubias = *reinterpret_cast<const f32x4*>(p.up_bias + 4 * g);
-  float ualpha = *p.up_alpha;
-  touch_v(ubias);
-  touch_s(ualpha);
-  const int lane_b = r * CROWB + g * 16;              // coarse voxel r of a row, channel chunk g
-  const int lane_a = lane * 16;                       // A fragment of a tap
-  const int lane_w = (2 * r) * ROWB + 8 * g;          // ring row: footprint column 2r (+1), channels 4g ..
-  // fine plane fz, footprint row j: taps of one parity combination (NZ z-taps x NY y-taps), both x parities
-  // (an emit is the producers' unit of overhead: 144 per step and workgroup, so it is branch-free: PReLU as
-  // fma(alpha, min(v, 0), max(v, 0)) -- the same bits as the select form for any slope -- and the x-range
-  // test as a per-lane AND mask computed once)
-  const unsigned xmask0 = (unsigned)(ox0 + 2 * r) < (unsigned)p.Wo ? 0xffffffffu : 0u;       // px = 0: fine x = ox0 + 2r
-  const unsigned xmask1 = (unsigned)(ox0 + 2 * r - 1) < (unsigned)p.Wo ? 0xffffffffu : 0u;   // px = 1: fine x = ox0 - 1 + 2r
-  auto emit = [&](char* dst, f32x4 acc, int px, bool row_in) {
-    // px = 0: footprint column 2r + 1; px = 1: column 2r
-    u32x2 o = u32x2{0u, 0u};
-    if (row_in) {
-      f32x4 v = acc + ubias;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(ualpha, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
-      const unsigned m = px ? xmask1 : xmask0;
-      o[0] = pack_bf16x2(v[0], v[1]) & m;
-      o[1] = pack_bf16x2(v[2], v[3]) & m;
-    }
-    if (r <= TW / 2) *reinterpret_cast<u32x2*>(dst + lane_w + (1 - px) * ROWB) = o;
-  };
-  // One fine plane, the rows j0, j0 + 8, j0 + 16 of this wave (all of one y-parity: NY y-taps), NZ
-  // z-taps: the NZ * NY * 3 weight fragments are read once, the coarse-voxel fragments of the next row
-  // are in flight while the current row is multiplied (left as dependent read -> MFMA chains in runtime
-  // loops the phase ran at the LDS latency: 70 us per 128^3 patch for the whole launch instead of 25).
-  auto produce_plane = [&](auto nz_c, auto ny_c, char* plane, int slotA, int slotB, int j0, bool z_in) {
-    constexpr int NZ = decltype(nz_c)::value, NY = decltype(ny_c)::value;
-    frag_t Af[NZ][NY][3];
-#pragma unroll
-    for (int zt = 0; zt < NZ; ++zt)
-#pragma unroll
-      for (int yt = 0; yt < NY; ++yt) {
-        // convt_ps tap order: odd parity (k = 2 on the nearer coarse voxel) then (k = 0); even: k = 1
-        const int kd = NZ == 2 ? (zt == 0 ? 2 : 0) : 1, kh = NY == 2 ? (yt == 0 ? 2 : 0) : 1;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-          Af[zt][yt][kw] = *reinterpret_cast<const frag_t*>(wupl + ((kd * 3 + kh) * 3 + kw) * 1024 + lane_a);
-      }
-    frag_t Bf[2][NZ][NY][2];
-    auto load_b = [&](int j, frag_t (&bq)[NZ][NY][2]) {
-      // odd fine row (j even): coarse rows j/2 (k = 2), j/2 + 1 (k = 0); even fine row: (j + 1)/2 (k = 1)
-      const int lr0 = NY == 2 ? j >> 1 : (j + 1) >> 1;
-#pragma unroll
-      for (int zt = 0; zt < NZ; ++zt)
-#pragma unroll
-        for (int yt = 0; yt < NY; ++yt) {
-          const char* brow = catl + (zt == 0 ? slotA : slotB) + (lr0 + yt) * CW * CROWB + lane_b;
-          bq[zt][yt][0] = *reinterpret_cast<const frag_t*>(brow);            // coarse column r     (local)
-          bq[zt][yt][1] = *reinterpret_cast<const frag_t*>(brow + CROWB);    // coarse column r + 1
-        }
-    };
-    load_b(j0, Bf[0]);
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int j = j0 + 8 * it;
-      if (j >= HH) break;                                   // wave-uniform
-      if (j + 8 < HH) load_b(j + 8, Bf[(it + 1) & 1]);
-      const int fy = oy0 - 1 + j;
-      const bool row_in = z_in && (unsigned)fy < (unsigned)p.Ho;
-      char* const dst = plane + j * HW * ROWB;
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      if (row_in && !DT_DBG(p, 1)) {
-#pragma unroll
-        for (int zt = 0; zt < NZ; ++zt)
-#pragma unroll
-          for (int yt = 0; yt < NY; ++yt) {
-            const frag_t b0 = Bf[it & 1][zt][yt][0], b1 = Bf[it & 1][zt][yt][1];
-            // even fine x = 2 (X0 + r): kw = 1 on coarse X0 + r = local column r + 1
-            acc0 = mma16<T>(Af[zt][yt][1], b1, acc0);
-            // odd fine x = 2 (X0 - 1 + r) + 1: (kw = 2, local column r) then (kw = 0, local column r + 1)
-            acc1 = mma16<T>(Af[zt][yt][2], b0, acc1);
-            acc1 = mma16<T>(Af[zt][yt][0], b1, acc1);
-          }
-      }
-      emit(dst, acc0, 0, row_in);
-      emit(dst, acc1, 1, row_in);
-    }
-  };
-  // `vw` = 0 .. 7: which eighth of the (plane, row) units (prologue: the wave itself; steady state: a
-  // producer wave takes two)
-  auto produce = [&](int fz_first, int count, int vw) {
-    using One = std::integral_constant<int, 1>;
-    using Two = std::integral_constant<int, 2>;
-    for (int pl = 0; pl < count; ++pl) {
-      const int fz = fz_first + pl;
-      char* const plane = smem + ((fz - z0 + 1) % R) * PLANE_B;
-      const bool z_in = (unsigned)fz < (unsigned)p.Do;
-      const bool zodd = (fz & 1) != 0;
-      // odd plane: (kd = 2, coarse (fz-1)/2) then (kd = 0, coarse (fz+1)/2); even plane: kd = 1, coarse fz/2
-      const int czA = zodd ? (fz - 1) >> 1 : fz >> 1, czB = (fz + 1) >> 1;
-      const int slotA = (((czA % CR) + CR) % CR) * CPLANE_B, slotB = (((czB % CR) + CR) % CR) * CPLANE_B;
-      const int j0 = (((vw - 3 * pl) % 8) + 8) % 8;       // rows j0, j0 + 8, (j0 + 16): balanced over the eighths
-      const bool yodd = (j0 & 1) == 0;                     // footprint row even <=> fine y odd
-      if (zodd) {
-        if (yodd) produce_plane(Two{}, Two{}, plane, slotA, slotB, j0, z_in);
-        else produce_plane(Two{}, One{}, plane, slotA, slotB, j0, z_in);
-      } else {
-        if (yodd) produce_plane(One{}, Two{}, plane, slotA, slotB, j0, z_in);
-        else produce_plane(One{}, One{}, plane, slotA, slotB, j0, z_in);
-      }
-    }
-  };
-
-  // ---- prologue (all 8 waves): ring planes z0-1 .. z0+4 (coarse planes z0/2-1 .. z0/2+2, three at a time)
-  const int cz0 = z0 >> 1;
-  cat_fetch(cz0 - 1, 3);
-  cat_commit(cz0 - 1, 3);
-  __syncthreads();
-  produce(z0 - 1, 3, wave);
-  __syncthreads();
-  cat_fetch(cz0 + 2, 1);
-  cat_commit(cz0 + 2, 1);
-  __syncthreads();
-  produce(z0 + 2, 3, wave);
-  __syncthreads();
-
-  auto ws_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  if (wave >= 4) {
-    // ======================================================= producers: ring planes of step s + 1
-    const int pw = wave - 4;
-    if (nsteps_z > 1) cat_fetch2((z0 + 5 + 1) >> 1);
-    for (int step = 0; step < nsteps_z; ++step) {
-      const bool more = step + 1 < nsteps_z;
-      const int a = z0 + step * TD + 5;                 // first new fine plane (odd)
-      if (more) cat_commit2((a + 1) >> 1);
-      ws_barrier();                                    // X: the coarse planes are in LDS
-      if (more) {
-        if (step + 2 < nsteps_z) cat_fetch2((a + 4 + 1) >> 1);
-        for (int vw = 2 * pw; vw < 2 * pw + 2; ++vw) produce(a, 4, vw);
-      }
-      ws_barrier();                                    // Y: ring planes of step s + 1 complete, step s consumed
-    }
-    return;
-  }
-
-  // ========================================================= consumers: convolution of step s
+  const int wrow = wave * NRO * HW * ROWB;             // consumer wave w: output rows 4w .. 4w+3 (footprint row 4w + kh)
   f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.cv_bias + 4 * g);
   touch_v(bias4);
   T* outp = (T*)p.out;
@@ -342,15 +297,17 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
   for (int ro = 0; ro < NRO; ++ro)
     o_off[ro] = (unsigned)(((oy0 + NRO * wave + ro) * p.Wo + ox0 + r) * p.ldo + 4 * g);
   const int64_t oplane = (int64_t)p.Ho * p.Wo * p.ldo;
+  ws_barrier(); ws_barrier(); ws_barrier(); ws_barrier();   // B1 .. B4 of the producers' prologue
 
   for (int step = 0; step < nsteps_z; ++step) {
     const int zb = step * TD;
     ws_barrier();                                      // X (the producers' hand-off among themselves)
-    // ---- conv: input plane c (z = z0 + zb - 1 + c) lives in ring slot (zb + c) % R
+    if (p.dbg & 2) { ws_barrier(); continue; }         // timing probes only
+    // ---- conv: input plane c (z = z0 + zb - 1 + c) lives in ring slot (zb + c + 1) % R
     f32x4 acc[4][NRO];
     int pofs[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c) % R) * PLANE_B + wrow;
+    for (int c = 0; c < 6; ++c) pofs[c] = ((zb + c + 1) % R) * PLANE_B + wrow;
     frag_t av[PD + 1][NRO];
     auto issue = [&](int it, frag_t (&dst)[NRO]) {
       const int c = it / J, j = it % J;
@@ -360,7 +317,6 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
     };
 #pragma unroll
     for (int q = 0; q < PD; ++q) issue(q, av[q]);
-    if (!DT_DBG(p, 2))
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       if (it + PD < NIT) issue(it + PD, av[(it + PD) % (PD + 1)]);
@@ -389,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void dectop_kernel(DecTopParams p) {
         const u32x2 hres = *reinterpret_cast<const u32x2*>(smem + pofs[zi + 1] + ((ro + 1) * HW + r + 1) * ROWB + 8 * g);
         f32x4 v = acc[zi][ro] + bias4;
         v += Raw4<T>::cvt(hres);
-        if (!DT_DBG(p, 4)) store4<T>(op + o_off[ro], v);
+        store4<T>(op + o_off[ro], v);
       }
     }
     ws_barrier();                                      // Y
@@ -422,8 +378,8 @@ int segmi_dectop_ok(int dtype, const segmi_act* in, const segmi_act* out) {
 }
 
 int segmi_dectop_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* up_frag,
-                     const float* up_bias, const float* up_alpha, const void* conv_packed,
-                     const float* conv_bias, void* stream) {
+                     const float* up_bias, const float* up_alpha, int up_alpha_in_unit_range,
+                     const void* conv_packed, const float* conv_bias, void* stream) {
   SEGMI_CHECK_ARG(segmi_dectop_ok(dtype, in, out), "dectop: layer not eligible (ask segmi_dectop_ok)");
   SEGMI_CHECK_ARG(up_frag && up_bias && up_alpha && conv_packed && conv_bias, "dectop: null operand");
   DecTopParams p{};
@@ -435,14 +391,18 @@ int segmi_dectop_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
   p.tz = dectop_tz(in->n, out->d, out->h, out->w);
   static const int dbg = getenv("SEGMI_DECTOP_DBG") ? atoi(getenv("SEGMI_DECTOP_DBG")) : 0;
   p.dbg = dbg;
+  p.alpha01 = up_alpha_in_unit_range ? 1 : 0;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dectop_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dectop_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, dectop::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dectop_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, dectop::LDS_BYTES);
     attr_done = true;
   }
   const unsigned grid = (unsigned)(p.N * p.ty * p.tx * p.tz);
-  hipLaunchKernelGGL(dectop_kernel, grid, 512, dectop::LDS_BYTES, (hipStream_t)stream, p);
+  if (p.alpha01) hipLaunchKernelGGL(dectop_kernel<true>, grid, 512, dectop::LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dectop_kernel<false>, grid, 512, dectop::LDS_BYTES, (hipStream_t)stream, p);
   SEGMI_LAUNCH_CHECK("dectop_fwd");
   return SEGMI_OK;
 }

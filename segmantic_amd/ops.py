@@ -220,12 +220,13 @@ def dectop_up_frag(w_t: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     return ws.permute(2, 0, 1).reshape(27, 4, 8, 16).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).reshape(27, 64, 8)
 
 
-def dectop_fwd(x, y, up_frag, up_bias, up_alpha, conv_packed, conv_bias) -> None:
+def dectop_fwd(x, y, up_frag, up_bias, up_alpha, conv_packed, conv_bias, alpha_in_unit_range=False) -> None:
     """inference: ConvTranspose3d(32 -> 16) + folded BN + PReLU, then conv(16 -> 16) + identity residual,
     one launch (segmi_dectop_fwd)"""
     ax, ay = act(x), act(y)
     check(lib.segmi_dectop_fwd(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(up_frag), _ptr(up_bias),
-                               _ptr(up_alpha), _ptr(conv_packed), _ptr(conv_bias), _stream()), "dectop_fwd")
+                               _ptr(up_alpha), int(bool(alpha_in_unit_range)), _ptr(conv_packed), _ptr(conv_bias),
+                               _stream()), "dectop_fwd")
 
 
 def conv3d_pair_ok(x, y_a, y_b) -> bool:

@@ -80,10 +80,17 @@ _LANES: dict = {}
 
 def default_lanes() -> int:
     """Streams that window groups alternate over when the predictor is this build's own network
-    (SEGMI_SW_LANES; 1 = everything on the caller's stream)."""
+    (SEGMI_SW_LANES; 1 = everything on the caller's stream).
+
+    Default 1 since round 3.  Two lanes are worth +0 .. +4 % on a warm box (21.4 vs 20.5, 21.3 vs 21.2,
+    22.9 vs 22.6 volumes/s in same-process A/Bs) but, in the first minute of a box's life, the two-lane
+    schedule repeatedly ran host-bound at 5 volumes/s (168 ms instead of 8 ms to enqueue a volume's window
+    groups, lane busy times unchanged, the one-lane run seconds later in the same process at 20+) -- the
+    round-2 driver figure of 17.5 against the builder's 21.3.  One lane does not have that failure mode;
+    bench.py reports both."""
     if os.environ.get("SEGMI_SERIAL"):
         return 1
-    return max(1, int(os.environ.get("SEGMI_SW_LANES", "2")))
+    return max(1, int(os.environ.get("SEGMI_SW_LANES", "1")))
 
 
 def _lane_streams(device, n: Optional[int] = None):

@@ -584,10 +584,12 @@ class UNetEngine:
 
     merge_eval_pairs = os.environ.get("SEGMI_MERGE_PAIRS", "1") != "0"
     # inference: transposed conv + conv-only unit of the full-resolution decoder as one launch
-    # (csrc/dectop.hip).  OFF by default: bit-identical to the two launches but not faster yet --
-    # 69 vs 59 us per 128^3 patch, 19.6 vs 20.4 volumes/s: its producer waves spend ~2000 instructions
-    # per step on 9-of-16-lane tiles; SEGMI_FUSE_EVAL_TOP=1 selects it.
-    fuse_eval_top = os.environ.get("SEGMI_FUSE_EVAL_TOP", "0") == "1"
+    # (csrc/dectop.hip): the 16-channel full-resolution tensor between them never reaches HBM (218 -> 84 MB
+    # per 128^3 patch).  Bit-identical to the two launches.  Round 2's version lost (69 vs 59 us per patch);
+    # with the producers re-tiled as 16 base voxels x 8 parity classes (round 3) it takes 46-49 us against
+    # 58 and the 512^3 benchmark gains 8-9 % (22.9 vs 21.0 volumes/s, same process order, one box).
+    # SEGMI_FUSE_EVAL_TOP=0 restores the two launches.
+    fuse_eval_top = os.environ.get("SEGMI_FUSE_EVAL_TOP", "1") != "0"
 
     def _merged_eval(self, ru, x, oshape):
         """(pack, bias, buffer) of the merged subunit-0 + residual convolution of a unit (inference,
@@ -971,9 +973,13 @@ class UNetEngine:
                 # transposed conv and the conv-only unit never reaches HBM (csrc/dectop.hip)
                 hit = lvl.get("_dectop")
                 if hit is None or hit[0] != self.weights_version:
-                    hit = (self.weights_version, ops.dectop_up_frag(up.w, sc), torch.addcmul(sh, up.b, sc))
+                    # (one host read of the slope per weights version: the kernel's PReLU fast path)
+                    a = float(ubn.alpha.reshape(-1)[0])
+                    hit = (self.weights_version, ops.dectop_up_frag(up.w, sc), torch.addcmul(sh, up.b, sc),
+                           0.0 <= a <= 1.0)
                     lvl["_dectop"] = hit
-                ops.dectop_fwd(cat, out, hit[1], hit[2], ubn.alpha, conv0.fwd_pack(), conv0.b)
+                ops.dectop_fwd(cat, out, hit[1], hit[2], ubn.alpha, conv0.fwd_pack(), conv0.b,
+                               alpha_in_unit_range=hit[3])
                 return
             au = self._buf(f"{p}au.e", oshape)
             pack, wsrc, bias = up.folded(sc, sh)

@@ -726,6 +726,8 @@ def test_fused_eval_decoder_top_is_bit_identical_and_used_by_the_sliding_window(
     img, _ = synthetic_batch(2, 64, 16, seed=13)
     img = img.to(DEV)
     outs = {}
+    default = UNetEngine.fuse_eval_top
+    assert default is True                       # round 3: the fused launch wins and is the default
     for flag in (False, True):
         UNetEngine.fuse_eval_top = flag
         try:
@@ -734,7 +736,7 @@ def test_fused_eval_decoder_top_is_bit_identical_and_used_by_the_sliding_window(
                 sw = sliding_window_inference(img[:1], (32, 32, 32), 4, net, 0.5, return_labels=True)
                 outs[(flag, "sw")] = (sw.logits.clone(), sw.labels.clone())
         finally:
-            UNetEngine.fuse_eval_top = False     # the default (the fused launch is opt-in: not faster yet)
+            UNetEngine.fuse_eval_top = default
     torch.cuda.synchronize()
     assert torch.equal(outs[False], outs[True])
     assert torch.equal(outs[(False, "sw")][0], outs[(True, "sw")][0])

@@ -1111,8 +1111,9 @@ def test_bn_bwd_sums_in_the_input_gradient_epilogue_match_the_separate_pass(shap
     assert float((db - db2).abs().max()) < 2e-4 * float(db.abs().max()) + 1e-3 * float(db.abs().mean())
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 16, 24, 32), (3, 6, 8, 40)])
-def test_fused_full_resolution_decoder_is_bit_identical_to_the_two_launches(shape):
+@pytest.mark.parametrize("slope", [0.25, 1.7, -0.3])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 16, 24, 32), (3, 6, 8, 40), (1, 2, 8, 8)])
+def test_fused_full_resolution_decoder_is_bit_identical_to_the_two_launches(shape, slope):
     """segmi_dectop_fwd: ConvTranspose3d(32 -> 16) + folded BN + PReLU -> conv(16 -> 16) + identity
     residual in one launch; same tap order and k-slot layout as the separate kernels => same bits."""
     n, d, h, w = shape
@@ -1122,7 +1123,7 @@ def test_fused_full_resolution_decoder_is_bit_identical_to_the_two_launches(shap
     scale = (rnd((16,), 504).abs() + 0.5).to(DEV)
     ub = (rnd((16,), 505) * 0.2).to(DEV)
     cb = (rnd((16,), 506) * 0.2).to(DEV)
-    alpha = torch.full((1,), 0.25, device=DEV)
+    alpha = torch.full((1,), slope, device=DEV)
     fine = (n, 2 * d, 2 * h, 2 * w, 16)
     # two launches
     up_pack = ops.wpack(torch.bfloat16, 2, wt, 32, 16, 3, scale=scale)
@@ -1134,10 +1135,15 @@ def test_fused_full_resolution_decoder_is_bit_identical_to_the_two_launches(shap
     # one launch
     out = torch.full(fine, float("nan"), dtype=torch.bfloat16, device=DEV)
     assert ops.dectop_ok(x, out)
-    ops.dectop_fwd(x, out, ops.dectop_up_frag(wt, scale), ub, alpha, cv_pack, cb)
+    ops.dectop_fwd(x, out, ops.dectop_up_frag(wt, scale), ub, alpha, cv_pack, cb, alpha_in_unit_range=0.0 <= slope <= 1.0)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out.float()).all())
     assert torch.equal(out, ref), f"max diff {float((out.float() - ref.float()).abs().max())}"
+    if 0.0 <= slope <= 1.0:        # the generic PReLU path gives the same bits
+        out2 = torch.full(fine, float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.dectop_fwd(x, out2, ops.dectop_up_frag(wt, scale), ub, alpha, cv_pack, cb, alpha_in_unit_range=False)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, ref)
     # independent check of the pair against torch (oracle semantics), bf16 tolerance
     xr = from_ndhwc(x)
     hq = F.prelu(F.conv_transpose3d(xr, q(wt.cpu() * scale.cpu().view(1, -1, 1, 1, 1), torch.bfloat16), ub.cpu(),
