@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--sw-batch", type=int, default=4, help="infer: windows per predictor call")
     ap.add_argument("--infer-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lane-ab", action="store_true", help="infer: only the default lane count (profiling runs)")
     ap.add_argument("--cpu-size", type=int, default=128)
     return ap.parse_args()
 
@@ -109,10 +110,10 @@ def csrc_hash() -> str:
 
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_traffic.json, written by scripts/make_profiles.py).  PMC counters cannot be
+    (profiles/r03_pmc_traffic.json, written by scripts/make_profiles.py).  PMC counters cannot be
     read from inside the process; the file is used only if it was measured on these very kernel
     sources (``source_hash``), otherwise traffic is null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         d = json.load(open(path))
         if d.get("source_hash") == csrc_hash():
@@ -297,6 +298,25 @@ def run_infer(args, rank, device, barrier, steps, warmup, lanes=None, net=None, 
     xa = torch.empty((per_launch, args.size, args.size, args.size, eng.kpad), dtype=eng.dtype, device=device)
     roof = roofline_of_top_conv(eng, key, per_launch * args.size ** 3, args.precision, xa, full_only=True)
     del xa
+    if roof and eng.eval_top_fused:
+        # the launch timed under this key is the FUSED full-resolution decoder (csrc/dectop.hip): transposed conv
+        # 32 -> 16 (+ folded BatchNorm + PReLU) and the 16 -> 16 conv with identity residual; the 16-channel tensor
+        # between them stays in LDS.  Algorithmic bytes: the coarse 32-channel input + the 16-channel output.
+        lvl = eng.levels
+        up = lvl["upconv"]
+        vox = per_launch * args.size ** 3
+        es = 2 if args.precision == "bf16" else 4
+        abytes = (vox // 8 * up.cin + vox * up.cout) * es
+        flops = vox * 2.0 * 27 * (up.cin * up.cout / 8.0 + up.cout * up.cout)
+        avg = roof["avg_launch_ms"]
+        gbps, ach = abytes / (avg * 1e-3) / 1e9, flops / (avg * 1e-3) / 1e12
+        roof.update({
+            "kernel": f"segmi::dectop_kernel -- MONAI layers model.{up.prefix} (ConvTranspose3d {up.cin}->{up.cout} + folded "
+                      f"BatchNorm + PReLU) and model.{top_conv(eng).prefix} ({up.cout}->{up.cout} k3 conv + identity residual) "
+                      f"as ONE launch, the tensor between them in LDS",
+            "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": abytes,
+            "mfma_view": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
+                          "peak_TFLOPs": MFMA_PEAK_TFLOPS[args.precision], "frac": ach / MFMA_PEAK_TFLOPS[args.precision]}})
     nl = st.get("lanes", lanes or default_lanes())
     if roof:
         roof["kernel"] += (f"; {per_launch} windows per launch (sw_batch {args.sw_batch} x internal group "
@@ -433,9 +453,12 @@ def main():
             r = run_infer(args, rank, device, barrier, isteps, iwarm, lanes=dl)
             dt = maxdt(r["dt"])
             other = 1 if dl > 1 else 2
-            r2 = run_infer(args, rank, device, barrier, isteps, 1, lanes=other, net=r["net"], vol=r["vol"])
-            dt2 = maxdt(r2["dt"])
-            same = bool(torch.equal(r["labels"], r2["labels"]))
+            if args.no_lane_ab:
+                r2, dt2, same = r, dt, True
+            else:
+                r2 = run_infer(args, rank, device, barrier, isteps, 1, lanes=other, net=r["net"], vol=r["vol"])
+                dt2 = maxdt(r2["dt"])
+                same = bool(torch.equal(r["labels"], r2["labels"]))
 
             def lane_fig(rr, d):
                 return {"lanes": rr["lanes"], "value": rr["steps"] * world / d, "ms_per_volume": d / rr["steps"] * 1e3,
@@ -450,7 +473,7 @@ def main():
                               "conv_TFLOP_per_volume": r["conv_TFLOP_per_volume"],
                               "conv_TFLOP_per_s": r["conv_TFLOP_per_volume"] * r["steps"] / dt,
                               "parallelism": f"replicas{world}"},
-                   "lanes": {"default": dl, "figures": [lane_fig(r, dt), lane_fig(r2, dt2)],
+                   "lanes": {"default": dl, "figures": [lane_fig(r, dt)] + ([] if args.no_lane_ab else [lane_fig(r2, dt2)]),
                              "labels_identical": same,
                              "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                              "hw_queues_set_before_runtime_init": bool(segmantic_amd.HW_QUEUES_EFFECTIVE),

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -64,13 +64,15 @@ alg = 8 * 128 ** 3 * 16 * 2 * 2
 # inference: the same layer on a full group of 16 windows (2048 workgroups)
 fi = newest("inf_fetch/*/*counter_collection.csv")
 wi = newest("inf_write/*/*counter_collection.csv")
-fki = [v for v, _ in launches(fi, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 524288)]
-wki = [v for v, _ in launches(wi, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 524288)]
+# (round 3: the fused decoder top, csrc/dectop.hip: 1024 workgroups of 512 threads per group of 16 windows)
+fki = [v for v, _ in launches(fi, "dectop_kernel", 524288)]
+wki = [v for v, _ in launches(wi, "dectop_kernel", 524288)]
 fki, wki = sorted(fki)[len(fki) // 2], sorted(wki)[len(wki) // 2]
-alg_i = 16 * 128 ** 3 * 16 * 2 * 2
+alg_i = 16 * (64 ** 3 * 32 + 128 ** 3 * 16) * 2
 json.dump({
     "source_hash": bench.csrc_hash(),
-    "kernel": kname + " (full-resolution 16->16 k3 conv forward with identity residual from LDS)",
+    "kernel": kname + " (training: full-resolution 16->16 k3 conv forward with identity residual from LDS; "
+              "inference: dectop_kernel, the fused ConvTranspose3d 32->16 + conv 16->16 of the decoder top)",
     "command": "SEGMI_SERIAL=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py "
                "--workload train --steps 1 --warmup 1 --no-cpu-baseline ; same with --pmc WRITE_SIZE (separate passes); "
                "inference: the same two passes of --workload infer (scripts/gpu_profiles.sh)",

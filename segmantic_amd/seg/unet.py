@@ -583,6 +583,7 @@ class UNetEngine:
                 and ops.conv3d_in_affine_ok(x, y, 3, 1))
 
     merge_eval_pairs = os.environ.get("SEGMI_MERGE_PAIRS", "1") != "0"
+    eval_top_fused = False      # set once an eval forward took the fused decoder-top launch (bench.py labels its roofline)
     # inference: transposed conv + conv-only unit of the full-resolution decoder as one launch
     # (csrc/dectop.hip): the 16-channel full-resolution tensor between them never reaches HBM (218 -> 84 MB
     # per 128^3 patch).  Bit-identical to the two launches.  Round 2's version lost (69 vs 59 us per patch);
@@ -978,8 +979,9 @@ class UNetEngine:
                     hit = (self.weights_version, ops.dectop_up_frag(up.w, sc), torch.addcmul(sh, up.b, sc),
                            0.0 <= a <= 1.0)
                     lvl["_dectop"] = hit
-                ops.dectop_fwd(cat, out, hit[1], hit[2], ubn.alpha, conv0.fwd_pack(), conv0.b,
-                               alpha_in_unit_range=hit[3])
+                self._timed(conv0.prefix + ":fwd", ops.dectop_fwd, cat, out, hit[1], hit[2], ubn.alpha,
+                            conv0.fwd_pack(), conv0.b, alpha_in_unit_range=hit[3])
+                self.eval_top_fused = True
                 return
             au = self._buf(f"{p}au.e", oshape)
             pack, wsrc, bias = up.folded(sc, sh)
