@@ -280,8 +280,20 @@ def run_infer(args, rank, device, barrier, steps, warmup, lanes=None, net=None, 
             return sliding_window_inference(vol, (args.size,) * 3, args.sw_batch, net, overlap=args.overlap,
                                             return_labels=True, return_logits=False, lanes=lanes,
                                             z_slab=z_slab, stats=stats)
-    for _ in range(warmup):
+    # Warm-up until steady: at least `warmup` volumes, then (at most 5 more) until two consecutive volumes
+    # agree within 15 %.  The first volumes of a leg can be host-bound by allocations -- 0.7 s in torch.empty
+    # for the 23 GB prediction cache right after the training leg returned its memory, and on some boxes
+    # several 100 ms per volume for a few volumes more (round 3: 4.3 volumes/s timed over such volumes, 22
+    # a second later) -- which says nothing about the path.  The warm-up times are reported.
+    warm = []
+    for i in range(max(1, warmup) + 5):
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
         run()
+        torch.cuda.synchronize()
+        warm.append((time.perf_counter() - tw) * 1e3)
+        if i + 1 >= max(1, warmup) and len(warm) >= 2 and abs(warm[-1] - warm[-2]) <= 0.15 * warm[-1]:
+            break
     eng = net._engine
     key = top_conv(eng).prefix + ":fwd"
     eng.timed = {key}
@@ -327,6 +339,8 @@ def run_infer(args, rank, device, barrier, steps, warmup, lanes=None, net=None, 
     return {"dt": dt, "steps": steps, "roofline": roof, "windows": nwin, "lanes": nl,
             "lane_busy_ms_per_volume": lane_busy,
             "host_enqueue_ms_per_volume": st.get("host_enqueue_s", 0.0) / steps * 1e3,
+            "host_enqueue_ms_each": [round(v * 1e3, 1) for v in st.get("host_enqueue_each_s", [])],
+            "warmup_ms_each": [round(v, 1) for v in warm],
             "conv_TFLOP_per_volume": nwin * args.size ** 3 * fpv / 1e12, "net": net, "vol": vol,
             "labels": res.labels}
 
@@ -464,6 +478,8 @@ def main():
                 return {"lanes": rr["lanes"], "value": rr["steps"] * world / d, "ms_per_volume": d / rr["steps"] * 1e3,
                         "lane_busy_ms_per_volume": rr["lane_busy_ms_per_volume"],
                         "host_enqueue_ms_per_volume": rr["host_enqueue_ms_per_volume"],
+                        "host_enqueue_ms_each": rr["host_enqueue_ms_each"],
+                        "warmup_ms_each": rr["warmup_ms_each"],
                         "top_conv_avg_launch_ms": rr["roofline"]["avg_launch_ms"] if rr["roofline"] else None}
             inf = {"metric": "sliding-window infer vols/s", "value": r["steps"] * world / dt, "unit": "volumes/s",
                    "steps": r["steps"], "ms_per_volume": dt / r["steps"] * 1e3, "dtype": args.precision,

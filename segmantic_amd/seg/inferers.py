@@ -293,6 +293,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                 main.wait_stream(st)
         if stats is not None:
             stats["host_enqueue_s"] = stats.get("host_enqueue_s", 0.0) + (_time.perf_counter() - t_enq)
+            stats.setdefault("host_enqueue_each_s", []).append(_time.perf_counter() - t_enq)
             stats["lanes"] = len(lanes) if lanes else 1
             stats.setdefault("lane_events", [[] for _ in lane_events])
             for dst, src in zip(stats["lane_events"], lane_events):
