@@ -40,9 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# the HIP runtime reads this when it initialises: set before anything can touch the GPU (the package
-# import sets it too; an exported value wins).  See segmantic_amd/seg/launch.py.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the HIP runtime reads this when it initialises: set before anything can touch the GPU, for multi-rank
+# runs only (segmantic_amd/__init__.py has the measurements; an exported value wins)
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 

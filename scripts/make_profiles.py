@@ -30,10 +30,12 @@ def run(script, *args):
 for wl, name in (("train", "train_b8_128_bf16"), ("infer", "infer_512_bf16")):
     st = newest(f"{wl}_stats/*/*kernel_stats.csv")
     shutil.copy(st, os.path.join(OUT, f"{tag}_{name}_kernel_stats.csv"))
-    steps = "13" if wl == "train" else "3"
+    steps = "13"
+    if wl == "infer":      # volumes of the run = launches of the blend kernel (the warm-up is adaptive since round 3)
+        steps = str(sum(int(r["Calls"]) for r in csv.DictReader(open(st)) if "sw_blend_kernel" in r["Name"]))
     open(os.path.join(OUT, f"{tag}_{name}_kernel_stats.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload infer --steps 2 --warmup 1' if wl == 'infer' else '--workload train --steps 10 --warmup 3'} --no-cpu-baseline\n"
-        f"# (both streams overlapped; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
+        f"# ({'both streams overlapped' if wl == 'train' else 'one lane (the default)'}; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
         + run("kstats.py", st, steps))
 shutil.copy(os.path.join(SRC, "bench_all.json"), os.path.join(OUT, f"{tag}_bench_all.json"))
 

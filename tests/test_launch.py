@@ -15,14 +15,20 @@ ECHO = str(ROOT / "tests" / "helpers" / "rank_echo.py")
 def test_runtime_env_is_set_at_package_import():
     # a fresh interpreter: importing the package must export the queue setting before any device call
     code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import segmantic_amd, torch; "
-            "print(os.environ['GPU_MAX_HW_QUEUES'], segmantic_amd.HW_QUEUES_EFFECTIVE, torch.cuda.is_initialized())")
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), segmantic_amd.HW_QUEUES_EFFECTIVE, torch.cuda.is_initialized())")
     env = dict(os.environ, PYTHONPATH=str(ROOT))
-    env.pop("GPU_MAX_HW_QUEUES", None)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    for k in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE"):
+        env.pop(k, None)
+    # a rank of a multi-process run (WORLD_SIZE is known at import time): 8 queues, before any device call
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, WORLD_SIZE="2"), capture_output=True, text=True,
+                         check=True).stdout
     assert out.split() == ["8", "True", "False"]
+    # single-GPU process: the runtime default stays (measured faster, segmantic_amd/__init__.py)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.split() == ["None", "True", "False"]
     # an exported value wins
     out = subprocess.run([sys.executable, "-c", "import os, segmantic_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"],
-                         env=dict(env, GPU_MAX_HW_QUEUES="16"), capture_output=True, text=True, check=True).stdout
+                         env=dict(env, GPU_MAX_HW_QUEUES="16", WORLD_SIZE="2"), capture_output=True, text=True, check=True).stdout
     assert out.strip() == "16"
 
 
@@ -44,7 +50,7 @@ def test_spawn_ranks_runs_the_ranks_and_returns_their_code(capfd, monkeypatch):
     assert rc == 0
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["world"] == 2 and line["sum"] == 3.0 and line["argv"] == ["--tag", "a"]
-    assert line["hwq"] == os.environ.get("GPU_MAX_HW_QUEUES", "8")
+    assert line["hwq"] == os.environ.get("GPU_MAX_HW_QUEUES", "8")     # spawn_ranks exports it to its ranks
     # a failing rank fails the launch
     rc = launch.spawn_ranks(2, [ECHO, "--fail-rank", "1"])
     capfd.readouterr()
