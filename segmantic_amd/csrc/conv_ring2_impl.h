@@ -227,22 +227,34 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
                  rplane32 = (unsigned)rplane, bplane32 = (unsigned)bplane;
   int slot0 = 0;                                                               // zb % R
   auto ring_slot = [&](int c) { const int v = slot0 + c; return v >= G::R ? v - G::R : v; };
-  for (int step = 0; step < nsteps_z; ++step) {
-    const int zb = step * G::TD;
-    const bool more = step + 1 < nsteps_z;
-    // ---- issue the global loads of the NEXT step's 4 new planes (z = z0 + zb + 5 .. + 8)
-    frag_t stg[G::TD][NLP];
+  // Staging loads: the 4 new planes step k + 1 computes from (z = z0 + 4k + 5 .. + 8) are committed to the
+  // ring at the end of step k and issued at its start.  PF2 = issue them a whole step earlier into a second
+  // set of 32 staging registers (the step body then exists twice, for static register indexing): tried in
+  // round 3 for the 16 -> 16 forward variants (MODE 0 / 1: 252 / 256 VGPRs, no spill) because time splits of
+  // the diagnostic build show the launch ADDING its memory time to its compute time (compute only 209 us,
+  // + loads 104, + stores 66 of 361) -- and measured SLOWER: 382-389 vs 361 us alone, 0.338 vs 0.317 ms inside
+  // the training step.  The loads are not late; left in the source, off.
+  constexpr bool PF2 = false;
+  auto issue_loads = [&](int k, frag_t (&dst)[G::TD][NLP]) {
+    const int zbk = k * G::TD;
+    const bool morek = k + 1 < nsteps_z;
 #pragma unroll
     for (int pl = 0; pl < G::TD; ++pl) {
-      const int z = z0 + zb + 5 + pl;
-      const char* pp = in_base + (unsigned)(zb + pl) * plane_b32;
-      const bool zok = more && z < p.Di && !RING2_DBG(p, 1);
+      const int z = z0 + zbk + 5 + pl;
+      const char* pp = in_base + (unsigned)(zbk + pl) * plane_b32;
+      const bool zok = morek && z < p.Di && !RING2_DBG(p, 1);
 #pragma unroll
       for (int q = 0; q < NLP; ++q) {
-        stg[pl][q] = frag_t{0u, 0u, 0u, 0u};
-        if (zok && g_off[q] >= 0) stg[pl][q] = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
+        dst[pl][q] = frag_t{0u, 0u, 0u, 0u};
+        if (zok && g_off[q] >= 0) dst[pl][q] = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
       }
     }
+  };
+  auto do_step = [&](const int step, frag_t (&stg)[G::TD][NLP], frag_t (&nxt)[G::TD][NLP]) {
+    const int zb = step * G::TD;
+    const bool more = step + 1 < nsteps_z;
+    if constexpr (PF2) issue_loads(step + 1, nxt);     // committed at the end of the NEXT step
+    else issue_loads(step, stg);                       // committed at the end of this step
     // residual rows of this step's outputs (4 planes x 2 rows), unless they are the input itself
     // (32-channel variant: 216 weight VGPRs leave no room for 32 more; it fetches them per plane
     // in the epilogue instead)
@@ -456,6 +468,20 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     }
     slot0 = slot0 + G::TD >= G::R ? slot0 + G::TD - G::R : slot0 + G::TD;
     if (!RING2_DBG(p, 32)) __syncthreads();
+  };
+  if constexpr (PF2) {
+    // two staging sets, alternating roles (static register indexing: the step body exists twice)
+    frag_t sA[G::TD][NLP], sB[G::TD][NLP];
+    issue_loads(0, sA);
+    for (int step = 0; step < nsteps_z; step += 2) {
+      do_step(step, sA, sB);
+      if (step + 1 < nsteps_z) do_step(step + 1, sB, sA);
+    }
+  } else {
+    for (int step = 0; step < nsteps_z; ++step) {
+      frag_t stg[G::TD][NLP];
+      do_step(step, stg, stg);
+    }
   }
 
   if constexpr (BSUM) {

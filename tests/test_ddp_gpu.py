@@ -277,3 +277,23 @@ def test_cli_train_with_two_gpu_ids_starts_its_own_ranks(tmp_path):
     assert "[rank 0/2]" in p.stdout and "[rank 1/2]" in p.stdout
     assert len(list(out.glob("epoch=0-val_loss=*-val_dice=*.ckpt"))) == 1      # rank 0 only
     assert not list(out.glob("ranks_*.json"))                                  # the hand-over file is gone
+
+
+def test_bench_infer_gpus_2_shards_one_volume_by_z_slabs():
+    """`bench.py --workload infer --gpus 2` (self-launched, gloo): next to the replica figure the line carries
+    ONE volume cut into z-slabs, one per rank, with the label all-gather as its only exchange (north_star's
+    inference split)."""
+    import json
+    import subprocess
+    root, env, py = _fresh_env()
+    p = subprocess.run([py, str(root / "bench.py"), "--gpus", "2", "--workload", "infer", "--steps", "1", "--warmup", "1",
+                        "--volume", "192", "--size", "64", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"] == "replicas2"
+    sh = out["one_volume_sharded"]
+    assert sh["value"] > 0 and sh["labels_shape"] == [192, 192, 192] and sh["label_allgather_ms"] >= 0
+    assert out["lanes"]["labels_identical"] is True
