@@ -256,6 +256,17 @@ int segmi_bn_act_bwd_reduce(int dtype, const segmi_act* dy, const segmi_act* x,
 int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double count,
                               const float* gamma, const float* invstd, float* dgamma,
                               float* dbeta, float* dalpha, float* coef, void* stream);
+/* The three calls above as ONE launch for small tensors (<= 32 MB, <= 256 channels in multiples of 4, no
+ * dropout): <= 256 workgroups reduce, the last one finalises and publishes the coefficients, all apply
+ * (a grid-wide hand-off through device-scope atomics; csrc/norm_act.hip).  red_partials: f32
+ * [segmi_bn_act_bwd_fused_rows(x)][3][c].  Same results as the three calls up to the f32 summation order of the
+ * partial rows.  Replaces autograd's BatchNorm / PReLU backward under monai ADN, monai_unet.py:114-124, 345. */
+int segmi_bn_act_bwd_fused_ok(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx);
+int segmi_bn_act_bwd_fused_rows(const segmi_act* x);
+int segmi_bn_act_bwd_fused(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* prelu_alpha, float* red_partials, const segmi_bn_bwd_fin* fin,
+                           void* stream);
 int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
                            const segmi_act* dx, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const float* prelu_alpha,

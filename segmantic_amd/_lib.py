@@ -109,6 +109,9 @@ SIGNATURES = {
     "segmi_bn_act_bwd_reduce": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32,
                                      C.POINTER(BnBwdFin), _P]),
     "segmi_bn_act_bwd_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _P, _P, _P]),
+    "segmi_bn_act_bwd_fused_ok": (_i, [_i, _AP, _AP, _AP]),
+    "segmi_bn_act_bwd_fused_rows": (_i, [_AP]),
+    "segmi_bn_act_bwd_fused": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwdFin), _P]),
     "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
     "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),
     "segmi_cast_copy": (_i, [_i, _AP, _i, _AP, _P]),

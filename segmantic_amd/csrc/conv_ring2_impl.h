@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) { bs0[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; bs1[jt] = bs0[jt]; bs2[jt] = bs0[jt]; }
   // z = xhat*gamma + beta = x*sc + sh with sc = invstd*gamma, sh = beta - mean*sc; sum dz*xhat is
-  // accumulated as sum dz*x and turned into invstd * (sum dz*x - mean * sum dz) per workgroup row
+  // accumulated as sum dz*(x - mean) and scaled by invstd per workgroup row
   float* bprm = tfs + 2 * CK;                       // [4][NT*16]: mean, invstd, sc, sh
   float balpha = 1.f;
   if constexpr (BSUM) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
             for (int jt = 0; jt < NT; ++jt) touch_v(resv[zi][ro][jt]);
       }
     }
-    f32x4 bsc4[NT], bsh4[NT];
+    f32x4 bsc4[NT], bsh4[NT], bmean4[NT];
     if constexpr (BSUM) {
       fetch_bx(2); fetch_bx(3);
 #pragma unroll
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       for (int jt = 0; jt < NT; ++jt) {
         bsc4[jt] = *reinterpret_cast<const f32x4*>(bprm + 2 * NT * 16 + jt * 16 + 4 * g);
         bsh4[jt] = *reinterpret_cast<const f32x4*>(bprm + 3 * NT * 16 + jt * 16 + 4 * g);
+        bmean4[jt] = *reinterpret_cast<const f32x4*>(bprm + jt * 16 + 4 * g);
       }
     }
     // ---- epilogue of this step
@@ -459,7 +460,9 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
                 float dz = d[e];
                 if (b_has_alpha && !(z > 0.f)) { bs2[jt][e] = fmaf(d[e], z, bs2[jt][e]); dz = balpha * d[e]; }
                 bs0[jt][e] += dz;
-                bs1[jt][e] = fmaf(dz, xr[e], bs1[jt][e]);
+                // sum dz * (x - mean), not sum dz * x corrected by mean * sum dz afterwards: the latter cancels
+                // badly when |mean| >> std; one subtraction per element
+                bs1[jt][e] = fmaf(dz, xr[e] - bmean4[jt][e], bs1[jt][e]);
               }
             } else
             store4<T>(op + o_off[ro] + jt * 16, v);
@@ -505,12 +508,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sacc += red[(w * 3 + which) * NT * 16 + ch];
-      if (which == 1) {           // sum dz*x -> sum dz*xhat
-        float s0 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s0 += red[(w * 3 + 0) * NT * 16 + ch];
-        sacc = bprm[1 * NT * 16 + ch] * fmaf(-bprm[ch], s0, sacc);
-      }
+      if (which == 1) sacc *= bprm[1 * NT * 16 + ch];   // sum dz*(x - mean) -> sum dz*xhat
       fin_store(&p.bpart[((int64_t)blockIdx.x * 3 + which) * p.Cout + nt0 * 16 + ch], sacc);
     }
     fin_tail_run<BnBwdFin, 256, offsetof(ConvParams, ft), offsetof(ConvParams, bbfin)>(p.bpart, smem);

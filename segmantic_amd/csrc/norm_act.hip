@@ -62,6 +62,7 @@ struct EwParams {
   int fin_on;
   FinTail ft;
   BnBwdFin bbfin;
+  unsigned epoch;      // bn_act_bwd_fused: value the last workgroup publishes in g_fused_flags[ft.ticket]
   // ADN dropout between the norm and the activation (MONAI "NDA"): element kept iff
   // hash(seed, logical NDHWC element index) >> 8 >= drop_thresh (= p * 2^24); kept values are
   // scaled by drop_scale = 1 / (1 - p).  drop_thresh == 0: no dropout.  The mask is never stored:
@@ -320,6 +321,154 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(EwParams p) {
   }
 }
 
+// ---------------------------------------------------------------- backward, one launch (small tensors)
+// reduce -> finalise -> apply of the BatchNorm + PReLU backward as ONE launch for the deep levels, whose
+// tensors (<= 32 MB) stay in the L2s / Infinity Cache between the two passes and whose three dependent
+// launches were pure latency on the main chain of the training step.  A grid-wide hand-off, not a
+// cooperative launch: <= 256 workgroups of 256 threads (all co-resident on 256 CUs beside whatever else
+// runs); every workgroup reduces its voxel range into a partial row and takes a ticket (fin_tail.h); the
+// last one folds the rows, writes dgamma / dbeta / dalpha, PUBLISHES coef with agent-scope stores and then
+// the launch's epoch in g_fused_flags[ticket]; the others poll that flag (s_sleep between polls) and then
+// apply over their own range.  The poll is bounded (~1 s): on expiry the workgroup writes NaN gradients --
+// a loud failure instead of a hung GPU -- and raises g_fused_timeouts.
+static __device__ unsigned int g_fused_flags[kFinTickets];
+static __device__ unsigned int g_fused_timeouts;
+static std::atomic<unsigned> g_fused_epoch{1};
+
+struct BnBwdFinPub {            // BnBwdFin whose coef stores are visible to the other XCDs before the flag
+  BnBwdFin f;
+  __device__ void operator()(const double* sums, double* red) const {
+    for (int cc = threadIdx.x; cc < f.c; cc += 256) {
+      fin_store(f.coef + cc, (float)(sums[cc] / f.count));
+      fin_store(f.coef + f.c + cc, (float)(sums[f.c + cc] / f.count));
+    }
+    BnBwdFin g = f;
+    g.coef = nullptr;
+    // dgamma / dbeta / dalpha are read after the launch only: plain stores
+    for (int cc = threadIdx.x; cc < f.c; cc += 256) {
+      if (f.dbeta) f.dbeta[cc] = (float)sums[cc];
+      if (f.dgamma) f.dgamma[cc] = (float)sums[f.c + cc];
+    }
+    if (f.dalpha) {
+      __syncthreads();
+      double t = 0.0;
+      for (int cc = threadIdx.x; cc < f.c; cc += 256) t += sums[2 * f.c + cc];
+      red[threadIdx.x] = t;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) *f.dalpha = (float)red[0];
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(EwParams p) {
+  constexpr int VEC = 4;
+  extern __shared__ double fused_lds[];          // fin tail: (3c + 1024) doubles; afterwards [6][c] floats
+  __shared__ float red[256 * 3 * VEC];
+  __shared__ int s_ok;
+  const int cg = p.c / VEC;
+  const int vpp = 256 / cg > 0 ? 256 / cg : 1;
+  const int tid = threadIdx.x;
+  const int my_cg = tid % cg, my_v = tid / cg;
+  const int64_t v0 = (int64_t)blockIdx.x * p.vpw;
+  const int64_t v1 = v0 + p.vpw < p.nvox ? v0 + p.vpw : p.nvox;
+  const T* x = (const T*)p.x;
+  const T* dy = (const T*)p.y;
+  T* o = (T*)p.o;
+  const bool has_alpha = p.alpha != nullptr;
+  const float alpha = has_alpha ? *p.alpha : 1.f;
+  const bool ok = my_v < vpp;
+  float mean[VEC], istd[VEC], gam[VEC], bet[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int ch = my_cg * VEC + k;
+    mean[k] = ok ? p.p0[ch] : 0.f;
+    istd[k] = ok ? p.p1[ch] : 0.f;
+    gam[k] = ok ? (p.p2 ? p.p2[ch] : 1.f) : 0.f;
+    bet[k] = ok ? (p.p3 ? p.p3[ch] : 0.f) : 0.f;
+  }
+  // ---- pass 1: partial sums of this workgroup's voxel range (as bn_act_bwd_reduce_kernel)
+  float s0[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) s0[k] = s1[k] = s2[k] = 0.f;
+  if (ok) {
+    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
+      float a[VEC], d[VEC];
+      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
+      loadv<T, VEC>(dy + v * p.ldy + my_cg * VEC, d);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float xh = (a[k] - mean[k]) * istd[k];
+        const float z = fmaf(xh, gam[k], bet[k]);
+        float dz = d[k];
+        if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[k], z, s2[k]); dz = alpha * d[k]; }
+        s0[k] += dz;
+        s1[k] = fmaf(dz, xh, s1[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    red[tid * 3 * VEC + k] = s0[k];
+    red[tid * 3 * VEC + VEC + k] = s1[k];
+    red[tid * 3 * VEC + 2 * VEC + k] = s2[k];
+  }
+  __syncthreads();
+  for (int q = tid; q < 3 * p.c; q += 256) {
+    const int which = q / p.c, ch = q % p.c;
+    const int g = ch / VEC, k = ch % VEC;
+    float acc = 0.f;
+    for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 3 * VEC + which * VEC + k];
+    fin_store(&p.out_partials[((int64_t)blockIdx.x * 3 + which) * p.c + ch], acc);
+  }
+  // ---- finalisation by the last workgroup, then the hand-off
+  const FinTail ft = kernarg_late<FinTail>(offsetof(EwParams, ft));
+  const bool last = fin_tail_run<BnBwdFinPub, 256, offsetof(EwParams, ft), offsetof(EwParams, bbfin)>(p.out_partials, fused_lds);
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this thread's coef stores have completed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&g_fused_flags[ft.ticket], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid == 0) {
+    int good = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(&g_fused_flags[ft.ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1u << 23)) { good = 0; atomicAdd(&g_fused_timeouts, 1u); break; }
+    }
+    s_ok = good;
+  }
+  __syncthreads();
+  const float poison = s_ok ? 0.f : __builtin_nanf("");
+  float* prm = reinterpret_cast<float*>(fused_lds);            // [2][c]: c0, c1
+  for (int i = tid; i < 2 * p.c; i += 256) prm[i] = fin_load1(p.coef + i) + poison;
+  __syncthreads();
+  // ---- pass 2: dx = gamma*invstd*(dz - c0 - xhat*c1) over the same range (as bn_act_bwd_apply_kernel)
+  if (ok) {
+    float c0[VEC], c1[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { c0[k] = prm[my_cg * VEC + k]; c1[k] = prm[p.c + my_cg * VEC + k]; }
+    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
+      float a[VEC], d[VEC];
+      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
+      loadv<T, VEC>(dy + v * p.ldy + my_cg * VEC, d);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float xh = (a[k] - mean[k]) * istd[k];
+        const float z = fmaf(xh, gam[k], bet[k]);
+        float dz = d[k];
+        if (has_alpha && !(z > 0.f)) dz = alpha * d[k];
+        a[k] = gam[k] * istd[k] * (dz - c0[k] - xh * c1[k]);
+      }
+      storev<T, VEC>(o + v * p.ldo + my_cg * VEC, a);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- misc elementwise
 template <typename TS, typename TD>
 __global__ void cast_copy_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t nvox,
@@ -505,6 +654,48 @@ int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
   const int grid = ew_blocks(p.nvox * (x->c / (v4 ? 4 : 1)));
   DISPATCH_TV(bn_act_bwd_apply_kernel, dtype, v4, grid, 6 * x->c * sizeof(float), (hipStream_t)stream, p);
   SEGMI_LAUNCH_CHECK("bn_act_bwd_apply");
+  return SEGMI_OK;
+}
+
+// one launch for reduce + finalise + apply (see bn_act_bwd_fused_kernel)
+static inline int fused_vpw(int64_t nvox) {
+  int64_t v = (nvox + 255) / 256;
+  if (v < 64) v = 64;
+  return (int)v;
+}
+int segmi_bn_act_bwd_fused_ok(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx) {
+  if (!act_ok(dy) || !act_ok(x) || !act_ok(dx) || (dtype != SEGMI_F32 && dtype != SEGMI_BF16)) return 0;
+  if (!same_shape(x, dy) || !same_shape(x, dx)) return 0;
+  if (!(vec4_ok(x, dtype) && vec4_ok(dy, dtype) && vec4_ok(dx, dtype)) || x->c > 256) return 0;
+  return act_voxels(x) * x->c * dtype_size(dtype) <= (32ll << 20) ? 1 : 0;
+}
+int segmi_bn_act_bwd_fused_rows(const segmi_act* x) {
+  return x ? (int)cdiv64(act_voxels(x), fused_vpw(act_voxels(x))) + kReserveRows : 0;
+}
+int segmi_bn_act_bwd_fused(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* prelu_alpha, float* red_partials, const segmi_bn_bwd_fin* fin,
+                           void* stream) {
+  SEGMI_CHECK_ARG(segmi_bn_act_bwd_fused_ok(dtype, dy, x, dx) && mean && invstd && red_partials && fin &&
+                      fin->count > 0 && fin->coef,
+                  "bn_act_bwd_fused: not eligible (ask segmi_bn_act_bwd_fused_ok) or bad arguments");
+  EwParams p{};
+  p.x = x->data; p.y = dy->data; p.o = dx->data; p.nvox = act_voxels(x); p.c = x->c;
+  p.ldx = x->ld; p.ldy = dy->ld; p.ldo = dx->ld;
+  p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha; p.coef = fin->coef;
+  p.out_partials = red_partials;
+  p.vpw = fused_vpw(p.nvox);
+  const int rows = (int)cdiv64(p.nvox, p.vpw);
+  p.fin_on = 1;
+  p.bbfin = BnBwdFin{x->c, fin->count, fin->dgamma, fin->dbeta, fin->dalpha, fin->coef};
+  size_t lds = fin_tail_arm(p, dim3((unsigned)rows), 256, 3 * x->c, 0);
+  if (lds < 2 * (size_t)x->c * sizeof(float)) lds = 2 * (size_t)x->c * sizeof(float);
+  p.epoch = g_fused_epoch.fetch_add(1);
+  if (p.epoch == 0) p.epoch = g_fused_epoch.fetch_add(1);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SEGMI_F32) hipLaunchKernelGGL(bn_act_bwd_fused_kernel<float>, rows, 256, lds, st, p);
+  else hipLaunchKernelGGL(bn_act_bwd_fused_kernel<bf16_t>, rows, 256, lds, st, p);
+  SEGMI_LAUNCH_CHECK("bn_act_bwd_fused");
   return SEGMI_OK;
 }
 

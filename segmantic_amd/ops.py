@@ -340,6 +340,26 @@ def bn_act_bwd_reduce(dy, x, mean, invstd, gamma, beta, prelu_alpha, partials,
                                       C.byref(bf) if bf is not None else None, _stream()), "bn_act_bwd_reduce")
 
 
+def bn_act_bwd_fused_ok(dy, x, dx) -> bool:
+    ady, ax, adx = act(dy), act(x), act(dx)
+    return bool(lib.segmi_bn_act_bwd_fused_ok(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx)))
+
+
+def bn_act_bwd_fused_rows(x) -> int:
+    a = act(x)
+    return int(lib.segmi_bn_act_bwd_fused_rows(C.byref(a)))
+
+
+def bn_act_bwd_fused(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, partials, fin) -> None:
+    """reduce + finalise + apply of the BatchNorm / PReLU backward in one launch (small tensors);
+    ``fin`` = (count, dgamma, dbeta, dalpha, coef)"""
+    ady, ax, adx = act(dy), act(x), act(dx)
+    bf = _bn_bwd_fin(fin)
+    check(lib.segmi_bn_act_bwd_fused(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx), _ptr(mean),
+                                     _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(prelu_alpha), _ptr(partials),
+                                     C.byref(bf), _stream()), "bn_act_bwd_fused")
+
+
 def bn_act_bwd_finalize(partials, rows, c, count, gamma, invstd, dgamma, dbeta, dalpha,
                         coef) -> None:
     check(lib.segmi_bn_act_bwd_finalize(_ptr(partials), rows, c, float(count), _ptr(gamma),

@@ -720,6 +720,13 @@ class UNetEngine:
         """``sums_rows`` > 0: the reduction's partial rows were written by the launch that produced dy
         (``_dgrad(..., bsum=)``); only finalisation and apply remain"""
         count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
+        if (not sums_rows and self.fuse_bn_bwd_small and self.fuse_fin and self.dropout_p <= 0.0
+                and ops.bn_act_bwd_fused_ok(dy, x_raw, dx)):
+            # deep levels: reduce + finalise + apply as ONE launch (csrc/norm_act.hip, bn_act_bwd_fused_kernel)
+            rows = ops.bn_act_bwd_fused_rows(x_raw)
+            ops.bn_act_bwd_fused(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
+                                 self._fstat(rows, bn.c), self._bwd_fin(bn, x_raw))
+            return
         if sums_rows:
             rows = sums_rows
             part = self._fstat(rows, bn.c)
@@ -1240,6 +1247,9 @@ class UNetEngine:
     # Finalisation of every BatchNorm reduction (forward statistics, backward sums) by the launch that
     # writes the partial rows (csrc/fin_tail.h); SEGMI_FUSE_FIN=0 keeps the separate one-workgroup launches
     fuse_fin = os.environ.get("SEGMI_FUSE_FIN", "1") != "0"
+    # BatchNorm / PReLU backward of the small (<= 32 MB) tensors as one launch with a grid-wide hand-off
+    # instead of reduce -> apply (SEGMI_FUSE_BN_BWD_SMALL=0: two launches)
+    fuse_bn_bwd_small = os.environ.get("SEGMI_FUSE_BN_BWD_SMALL", "1") != "0"
     # BatchNorm-backward reduction in the epilogue of the input-gradient launch that produces its
     # operand (segmi_bn_bwd_sums); SEGMI_FUSE_BN_BWD=0 keeps the separate two-tensor pass (A/B)
     fuse_bn_bwd = os.environ.get("SEGMI_FUSE_BN_BWD", "1") != "0"

@@ -1052,6 +1052,34 @@ def test_confusion_matrix_metric_and_empty_dice_aggregate_match_monai_rule():
     assert float(ref_dice_metric(pred[:1, :, :4, :4, :4], zeros, K)[1]) == 0.0
 
 
+def test_bn_bwd_sums_stay_accurate_when_the_mean_dwarfs_the_spread():
+    """the fused epilogue accumulates sum dz*(x - mean); the round-2 form sum dz*x - mean*sum dz
+    cancelled when |mean| >> std.  x = 50 + N(0, 1): dgamma from the fused sums must match an f64 reference."""
+    n, d, h, w, c = 2, 32, 64, 128, 16
+    g = torch.Generator().manual_seed(5)
+    dy = rnd((n, c, d, h, w), 411, 0.5)
+    xr = torch.randn((n, c, d, h, w), generator=g) + 50.0
+    dyd, xd = to_ndhwc(dy, torch.bfloat16), to_ndhwc(xr, torch.bfloat16)
+    pk = ops.wpack(torch.bfloat16, 1, rnd((c, c, 3, 3, 3), 413, 0.08).to(DEV), c, c, 3)
+    xq = from_ndhwc(xd).double()
+    mean = xq.mean((0, 2, 3, 4))
+    invstd = 1.0 / torch.sqrt(xq.var((0, 2, 3, 4), unbiased=False) + 1e-5)
+    gamma, beta = (rnd((c,), 416) + 1.5), (rnd((c,), 417) * 0.3)
+    dx = torch.empty_like(dyd)
+    rows = ops.conv3d_stats_rows(dyd, dx, 3, 1)
+    part = torch.zeros((rows, 3, c), device=DEV)
+    dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty((2, c), device=DEV)
+    ops.conv3d_fwd(dyd, dx, pk, None, 1, None, 3, 1,
+                   bn_bwd=(xd, mean.float().to(DEV), invstd.float().to(DEV), gamma.to(DEV), beta.to(DEV), None, part),
+                   bn_bwd_fin=(n * d * h * w, dg, db, None, coef))
+    torch.cuda.synchronize()
+    gq = from_ndhwc(dx).double()                                   # the stored gradient the sums are taken of
+    xhat = (xq - mean.view(1, -1, 1, 1, 1)) * invstd.view(1, -1, 1, 1, 1)
+    want_dg, want_db = (gq * xhat).sum((0, 2, 3, 4)), gq.sum((0, 2, 3, 4))
+    assert float((dg.cpu().double() - want_dg).abs().max()) < 2e-4 * float(want_dg.abs().max()) + 1e-3 * float(want_dg.abs().mean())
+    assert float((db.cpu().double() - want_db).abs().max()) < 2e-4 * float(want_db.abs().max()) + 1e-3 * float(want_db.abs().mean())
+
+
 @pytest.mark.parametrize("shape,residual", [((2, 32, 64, 128), "in"), ((2, 33, 60, 120), "other"), ((4, 16, 64, 128), None)])
 def test_bn_bwd_sums_in_the_input_gradient_epilogue_match_the_separate_pass(shape, residual):
     """segmi_bn_bwd_sums: the ring kernel's input-gradient launch also writes the partial rows of the
@@ -1395,3 +1423,78 @@ def test_ring_kernel_predicates_refuse_samples_beyond_its_32_bit_addressing():
     torch.cuda.synchronize()
     ref = F.conv3d(from_ndhwc(x), q(w, torch.bfloat16), padding=1)
     assert relerr(from_ndhwc(y), ref) < BF16_RTOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,sp,n,with_alpha", [(32, (32, 32, 32), 8, True), (64, (16, 16, 16), 8, True),
+                                               (256, (8, 8, 8), 8, True), (128, (8, 8, 8), 2, False),
+                                               (48, (5, 6, 7), 2, True), (16, (9, 10, 12), 1, True)])
+def test_bn_backward_as_one_launch_matches_the_three_calls(c, sp, n, with_alpha, dtype):
+    """segmi_bn_act_bwd_fused (small tensors): reduce + finalise + apply behind a grid-wide hand-off.  Same
+    dgamma / dbeta / dalpha / coef as the separate calls up to the summation order of the partial rows; dx
+    equal up to the rounding flips those last bits cause; bitwise reproducible."""
+    x = rnd((n, c) + sp, 61, 2.0)
+    dy = rnd((n, c) + sp, 62)
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    mean = (rnd((c,), 63) * 0.5).to(DEV)
+    invstd = (rnd((c,), 64).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd((c,), 65) + 1.5).to(DEV), (rnd((c,), 66) * 0.3).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV) if with_alpha else None
+    count = n * sp[0] * sp[1] * sp[2]
+    assert ops.bn_act_bwd_fused_ok(dyd, xd, xd)
+
+    def outs():
+        return (torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV),
+                torch.full((1,), float("nan"), device=DEV) if with_alpha else None, torch.full((2, c), float("nan"), device=DEV))
+
+    def three():
+        dg, db, da, coef = outs()
+        rows = ops.bn_act_bwd_rows(xd)
+        part = torch.zeros((rows, 3, c), device=DEV)
+        ops.bn_act_bwd_reduce(dyd, xd, mean, invstd, gamma, beta, alpha, part)
+        ops.bn_act_bwd_finalize(part, rows, c, count, gamma, invstd, dg, db, da, coef)
+        dx = torch.empty_like(xd)
+        ops.bn_act_bwd_apply(dyd, xd, dx, mean, invstd, gamma, beta, alpha, coef)
+        torch.cuda.synchronize()
+        return dx, [dg, db, coef] + ([da] if with_alpha else [])
+
+    def one():
+        dg, db, da, coef = outs()
+        rows = ops.bn_act_bwd_fused_rows(xd)
+        part = torch.zeros((rows, 3, c), device=DEV)
+        dx = torch.full_like(xd, float("nan"))
+        ops.bn_act_bwd_fused(dyd, xd, dx, mean, invstd, gamma, beta, alpha, part, (count, dg, db, da, coef))
+        torch.cuda.synchronize()
+        return dx, [dg, db, coef] + ([da] if with_alpha else [])
+
+    dx0, ref = three()
+    dx1, got = one()
+    dx2, again = one()
+    for a, g_, g2 in zip(ref, got, again):
+        assert bool(torch.isfinite(g_).all())
+        assert float((a - g_).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7
+        assert torch.equal(g_, g2)
+    assert torch.equal(dx1, dx2)
+    assert bool(torch.isfinite(dx1.float()).all())
+    tol_dx = 1e-5 if dtype == torch.float32 else 1e-2
+    assert float((dx0.float() - dx1.float()).abs().max()) <= tol_dx * float(dx0.float().abs().max())
+    # tensors beyond 32 MB are refused by the query
+    big = torch.empty((8, 64, 64, 64, 16), dtype=torch.bfloat16, device=DEV)
+    assert not ops.bn_act_bwd_fused_ok(big, big, big)
+
+
+def test_cu_masked_stream_runs_kernels():
+    """segmi_stream_create_cumask (hipExtStreamCreateWithCUMask): a stream restricted to 64 CUs computes the
+    same bits as the default stream (measured as a scheduling tool in round 3 and not used: DESIGN section 6)."""
+    s = ops.cu_masked_stream(64)
+    x = to_ndhwc(rnd((1, 16, 8, 16, 32), 71), torch.bfloat16)
+    sc, sh = (rnd((16,), 72) + 1.5).to(DEV), rnd((16,), 73).to(DEV)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    ops.bn_act_fwd(x, y0, sc, sh, None)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        ops.bn_act_fwd(x, y1, sc, sh, None)
+    s.synchronize()
+    assert torch.equal(y0, y1)
+    with pytest.raises(RuntimeError):
+        ops.cu_masked_stream(13)
