@@ -180,6 +180,17 @@ int segmi_dectop_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
  * out_b = conv_b(in) + bias_b.  w_a / w_b are torch-layout f32 [cout][cin][27].
  * segmi_conv3d_pair_ok() says whether the layer qualifies (1) or needs two segmi_conv3d_fwd (0).
  * Replaces the two torch.nn.Conv3d of monai ResidualUnit, monai_unet.py:114-124. */
+/* Window views (inference): sample n of `in` is not a slice of a dense batch but the (d, h, w) block that starts
+ * offset[n] elements into a larger single-channel volume (`in->data` = the volume, row / plane strides in
+ * elements), with ZERO padding at the block's own borders -- the windows of MONAI's sliding_window_inference
+ * (monai_unet.py:354-356, 637-639, 665) read in place, instead of being gathered into a batch first.  <= 16
+ * windows per call; offsets and strides multiples of 4 elements. */
+typedef struct segmi_windows {
+  int32_t count;
+  int32_t row_stride;
+  int64_t plane_stride;
+  int64_t offset[16];
+} segmi_windows;
 int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
                          const segmi_act* out_b);
 /* The same pairing for MFMA layers (the stride-2 first subunit + residual convolution of the deeper
@@ -197,6 +208,7 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
                           const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
                           const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,
                           const segmi_bn_fin* stats_fin_a /* nullable; needs stats_partials_a */,
+                          const segmi_windows* windows /* nullable: `in` samples are window views */,
                           void* stream);
 
 /* ConvTranspose3d k3 s2 p1 (output extent 2*in or 2*in-1 per dim, taken from `out`),

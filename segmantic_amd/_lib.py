@@ -43,6 +43,13 @@ class InAffine(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("prelu_alpha", C.c_void_p)]
 
 
+class Windows(C.Structure):
+    """``segmi_windows``: the samples of an input are window views into a larger single-channel volume."""
+
+    _fields_ = [("count", C.c_int32), ("row_stride", C.c_int32), ("plane_stride", C.c_int64),
+                ("offset", C.c_int64 * 16)]
+
+
 class BnFin(C.Structure):
     """``segmi_bn_fin``: BatchNorm statistics finalised by the launch that produces the partial rows."""
 
@@ -94,7 +101,8 @@ SIGNATURES = {
     "segmi_dectop_ok": (_i, [_i, _AP, _AP]),
     "segmi_dectop_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _P, _P, _P]),
     "segmi_conv3d_pair_ok": (_i, [_i, _AP, _AP, _AP]),
-    "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, C.POINTER(BnFin), _P]),
+    "segmi_conv3d_fwd_pair": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, _P, _i, C.POINTER(BnFin),
+                                   C.POINTER(Windows), _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),
     "segmi_convT3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, C.POINTER(BnFin), _P]),
     "segmi_conv3d_wgrad_workspace": (_i64, [_i, _AP, _AP, _i, _i]),

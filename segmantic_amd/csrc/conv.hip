@@ -25,7 +25,7 @@ int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const f
                    const float* bias, const float* alpha, const segmi_act* res, float* stats,
                    int stride, hipStream_t st, const segmi_act* out2 = nullptr,
                    const float* w2 = nullptr, const float* bias2 = nullptr,
-                   const segmi_bn_fin* fin = nullptr);
+                   const segmi_bn_fin* fin = nullptr, const segmi_windows* win = nullptr);
 int conv_small_fwd_rows(const segmi_act* out);
 
 struct DirectParams {
@@ -169,9 +169,19 @@ int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
 int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
                           const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
                           const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,
-                          const segmi_bn_fin* stats_fin_a, void* stream) {
+                          const segmi_bn_fin* stats_fin_a, const segmi_windows* windows, void* stream) {
   SEGMI_CHECK_ARG(!stats_fin_a || (stats_partials_a && bn_fin_ok(stats_fin_a)),
                   "conv3d_fwd_pair: stats_fin_a needs stats_partials_a and its output pointers");
+  if (windows) {
+    const int es = dtype_size(dtype);
+    bool ok = in && in->c == 1 && in->ld == 1 && windows->count == in->n && windows->count >= 1 && windows->count <= 16 &&
+              windows->row_stride >= in->w && windows->row_stride % 4 == 0 && in->w % 4 == 0 &&
+              windows->plane_stride >= (int64_t)windows->row_stride * in->h && windows->plane_stride % 4 == 0 &&
+              ((uintptr_t)in->data % (4 * es)) == 0;
+    for (int i = 0; ok && i < windows->count; ++i) ok = windows->offset[i] >= 0 && windows->offset[i] % 4 == 0;
+    SEGMI_CHECK_ARG(ok, "conv3d_fwd_pair: bad window views (single channel, <= 16 windows, 4-element aligned "
+                        "offsets and strides)");
+  }
   SEGMI_CHECK_ARG(segmi_conv3d_pair_ok(dtype, in, out_a, out_b),
                   "conv3d_fwd_pair: not a small-Cin k3 pair (ask segmi_conv3d_pair_ok first)");
   SEGMI_CHECK_ARG(w_a && w_b && (stride == 1 || stride == 2), "conv3d_fwd_pair: bad arguments");
@@ -181,7 +191,7 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
   SEGMI_CHECK_ARG(!(stats_partials_a && prelu_alpha_a),
                   "conv3d_fwd_pair: fused statistics are taken before PReLU");
   return conv_small_fwd(dtype, in, out_a, w_a, bias_a, prelu_alpha_a, nullptr, stats_partials_a,
-                        stride, (hipStream_t)stream, out_b, w_b, bias_b, stats_fin_a);
+                        stride, (hipStream_t)stream, out_b, w_b, bias_b, stats_fin_a, windows);
 }
 
 int segmi_conv3d_split_act_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,

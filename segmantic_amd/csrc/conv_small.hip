@@ -28,6 +28,13 @@ struct SmallConvParams {
   const float* bias2;
   int ldo2;
   int vec;   // Cin == 1 rows can be staged with 4-element loads (dense, 4-aligned W and base)
+  // window views (segmi_windows): sample n of the input is the (Di, Hi, Wi) block that starts woff[n]
+  // elements into a larger single-channel volume with row / plane strides wsy / wsz -- the sliding-window
+  // driver's windows, read in place instead of being gathered into a batch first.  nwin == 0: dense batch.
+  int nwin;
+  int wsy;
+  int64_t wsz;
+  int64_t woff[16];
   // BatchNorm statistics finalised by the last workgroup of this launch (fin_tail.h)
   int fin_on;
   FinTail ft;
@@ -78,7 +85,9 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   // else (212 quarter-rate integer multiplies per wave): a thread now owns one x position and walks
   // the halo rows with running (ci, hz, hy) counters and a running 32-bit element offset from the
   // wave-uniform tile origin; all loads are issued before the first LDS store.
-  const T* tile = (const T*)p.in + ((((int64_t)n * p.Di + iz0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi;
+  const bool win = p.nwin > 0;                         // (windows: single channel, ldi = 1)
+  const T* tile = win ? (const T*)p.in + p.woff[n] + (int64_t)iz0 * p.wsz + (int64_t)iy0 * p.wsy + ix0
+                      : (const T*)p.in + ((((int64_t)n * p.Di + iz0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi;
   const int hx = tid % HW;
   const bool xlive = tid < RPI * HW && (unsigned)(ix0 + hx) < (unsigned)p.Wi;
   T stg[NIT];
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   Vec4 vstg[CIN == 1 ? NITV : 1];
   const bool vec = CIN == 1 && p.vec;
   if (vec) {
-    const int sy = p.Wi, sz = p.Hi * sy;
+    const int64_t sy = win ? p.wsy : p.Wi, sz = win ? p.wsz : (int64_t)p.Hi * p.Wi;
 #pragma unroll
     for (int k = 0; k < NITV; ++k) {
       const int gi = tid + 256 * k;
@@ -503,12 +512,17 @@ static int launch_small_fwd_cin(const SmallConvParams& p, int cin, hipStream_t s
 int conv_small_fwd(int dtype, const segmi_act* in, const segmi_act* out, const float* w,
                    const float* bias, const float* alpha, const segmi_act* res, float* stats,
                    int stride, hipStream_t st, const segmi_act* out2, const float* w2,
-                   const float* bias2, const segmi_bn_fin* fin) {
+                   const float* bias2, const segmi_bn_fin* fin, const segmi_windows* win) {
   SmallConvParams p{};
   if (fin && stats) { p.fin_on = 1; p.bfin = bn_fin_from(fin, out->c); }
+  if (win) {
+    p.nwin = win->count; p.wsy = win->row_stride; p.wsz = win->plane_stride;
+    for (int i = 0; i < win->count; ++i) p.woff[i] = win->offset[i];
+  }
   if (out2) { p.out2 = out2->data; p.w2 = w2; p.bias2 = bias2; p.ldo2 = out2->ld; }
   p.vec = in->c == 1 && in->ld == 1 && in->w % 4 == 0 &&
           ((uintptr_t)in->data % (4 * (dtype == SEGMI_F32 ? 4 : 2))) == 0;
+  if (win) SEGMI_CHECK_ARG(p.vec, "conv3d: window views need the 4-element staging path");
   p.in = in->data; p.out = out->data; p.w = w; p.bias = bias; p.alpha = alpha;
   p.res = res ? res->data : nullptr; p.ldr = res ? res->ld : 0; p.stats = stats;
   p.N = in->n; p.Di = in->d; p.Hi = in->h; p.Wi = in->w; p.Do = out->d; p.Ho = out->h; p.Wo = out->w;

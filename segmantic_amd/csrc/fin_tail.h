@@ -62,12 +62,6 @@ static inline size_t fin_tail_arm(P& p, dim3 grid, int threads, int width, size_
 __device__ __forceinline__ void fin_store(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void fin_load2(const float* p, float& a, float& b) {   // 8-byte aligned
-  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  a = __uint_as_float((unsigned)u);
-  b = __uint_as_float((unsigned)(u >> 32));
-}
 __device__ __forceinline__ float fin_load1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

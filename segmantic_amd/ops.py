@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SEGMI_BF16, SEGMI_F32, Act, BnBwdFin, BnBwdSums, BnFin, InAffine, check, lib
+from ._lib import SEGMI_BF16, SEGMI_F32, Act, BnBwdFin, BnBwdSums, BnFin, InAffine, Windows, check, lib
 
 _DT = {torch.float32: SEGMI_F32, torch.bfloat16: SEGMI_BF16}
 
@@ -36,8 +36,46 @@ def _require_device(t: torch.Tensor) -> None:
             % t.device)
 
 
-def act(t: torch.Tensor) -> Act:
+class WindowBatch:
+    """A batch of sliding windows read IN PLACE: ``volume`` [D, H, W] (contiguous, single channel, compute
+    dtype) and the (z, y, x) origins of <= 16 windows of extent ``roi`` that lie inside it.  Quacks like the
+    NDHWC tensor [n, *roi, 1] it stands for (``shape``, ``dtype``, ``device``); only the first-layer pair
+    kernel (``conv3d_fwd_pair``) reads it (``segmi_windows``)."""
+
+    def __init__(self, volume: torch.Tensor, starts, roi):
+        if volume.dim() != 3 or not volume.is_contiguous():
+            raise ValueError("WindowBatch: volume must be a contiguous [D, H, W] tensor")
+        self.volume, self.roi = volume, tuple(int(r) for r in roi)
+        self.starts = [tuple(int(v) for v in s) for s in starts]
+        D, H, W = volume.shape
+        if not 1 <= len(self.starts) <= SW_MAX_WINDOWS:
+            raise ValueError("WindowBatch: 1 .. 16 windows")
+        for s in self.starts:
+            if any(a < 0 or a + r > n for a, r, n in zip(s, self.roi, (D, H, W))):
+                raise ValueError(f"WindowBatch: window {s} + {self.roi} leaves the volume {tuple(volume.shape)}")
+        self.shape = (len(self.starts),) + self.roi + (1,)
+        self.dtype, self.device, self.is_cuda = volume.dtype, volume.device, volume.is_cuda
+
+    @staticmethod
+    def eligible(volume_shape, starts, roi) -> bool:
+        """4-element alignment of rows and window origins (the kernel's staging loads)"""
+        return (volume_shape[2] % 4 == 0 and roi[2] % 4 == 0 and (volume_shape[1] * volume_shape[2]) % 4 == 0
+                and all(s[2] % 4 == 0 for s in starts))
+
+    def windows(self) -> Windows:
+        D, H, W = self.volume.shape
+        w = Windows()
+        w.count, w.row_stride, w.plane_stride = len(self.starts), W, H * W
+        for i, (z, y, x) in enumerate(self.starts):
+            w.offset[i] = (z * H + y) * W + x
+        return w
+
+
+def act(t) -> Act:
     """NDHWC view descriptor of a 5-D tensor whose last dim has stride 1."""
+    if isinstance(t, WindowBatch):
+        n, d, h, w, _ = t.shape
+        return Act(t.volume.data_ptr(), n, d, h, w, 1, 1)
     _require_device(t)
     if t.dim() != 5:
         raise ValueError(f"expected a 5-D NDHWC tensor, got shape {tuple(t.shape)}")
@@ -238,9 +276,10 @@ def conv3d_fwd_pair(x, y_a, w_a, bias_a, y_b, w_b, bias_b, stride, prelu_alpha_a
                     stats_a=None, stats_fin_a=None) -> None:
     """Subunit-0 and residual convolution of a small-Cin ResidualUnit in one launch."""
     ax, aa, ab = act(x), act(y_a), act(y_b)
+    win = C.byref(x.windows()) if isinstance(x, WindowBatch) else None
     check(lib.segmi_conv3d_fwd_pair(dtype_code(x), C.byref(ax), C.byref(aa), _ptr(w_a), _ptr(bias_a),
                                     _ptr(prelu_alpha_a), _ptr(stats_a), C.byref(ab), _ptr(w_b),
-                                    _ptr(bias_b), stride, _bn_fin(stats_fin_a), _stream()), "conv3d_fwd_pair")
+                                    _ptr(bias_b), stride, _bn_fin(stats_fin_a), win, _stream()), "conv3d_fwd_pair")
 
 
 def conv3d_split_act_ok(x, y, ksize, stride) -> bool:

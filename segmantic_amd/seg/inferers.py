@@ -223,12 +223,20 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     # (The streaming fallback keeps the enlarged groups: gather and scatter-add chunk them by 16.)
     if into is not None:
         sw_batch_size = int(sw_batch_size) * group_factor()
+    # Windows read in place (own network, one input channel, no padding, 4-element aligned rows and origins):
+    # the volume is cast to the compute dtype once and the first-layer kernel takes the windows as views
+    # (ops.WindowBatch / segmi_windows) -- no gather pass, no window batch in HBM.  SEGMI_SW_VIEWS=0: gather.
+    views_ok = (into is not None and Cin == 1 and not any(pad_lo) and all(o >= r for o, r in zip(orig, roi))
+                and os.environ.get("SEGMI_SW_VIEWS", "1") != "0" and sw_batch_size <= ops.SW_MAX_WINDOWS
+                and ops.WindowBatch.eligible(orig, wins_u[lo:hi], roi)
+                and getattr(owner, "window_views_ok", lambda d: False)(window_dtype))
     for b in range(B):
         acc = cnt = cache = None
         K = None
         deferred = False
         main = torch.cuda.current_stream(dev)
         forked = False
+        volc = img[b].reshape(orig).to(window_dtype) if views_ok else None
         for gi, g0 in enumerate(range(lo, hi, sw_batch_size)):
             grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
             slot = g0 - lo
@@ -245,10 +253,13 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                     if stats is not None:
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
-                                       device=dev)
-                    ops.sw_gather(img, b, grp, wbuf)
-                    ok = into(wbuf.permute(0, 4, 1, 2, 3), cache[slot:slot + len(grp)], lane)
+                    if volc is not None:
+                        ok = into(ops.WindowBatch(volc, grp, roi), cache[slot:slot + len(grp)], lane)
+                    else:
+                        wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
+                                           device=dev)
+                        ops.sw_gather(img, b, grp, wbuf)
+                        ok = into(wbuf.permute(0, 4, 1, 2, 3), cache[slot:slot + len(grp)], lane)
                     if stats is not None:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record()
@@ -261,6 +272,13 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
             if stats is not None and lanes is None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
+            if cache is not None and into is not None and volc is not None and \
+                    into(ops.WindowBatch(volc, grp, roi), cache[slot:slot + len(grp)]):
+                if stats is not None and lanes is None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    lane_events[0].append((e0, e1))
+                continue                                   # windows read in place, predicted straight into the cache
             wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
                                device=dev)
             ops.sw_gather(img, b, grp, wbuf)

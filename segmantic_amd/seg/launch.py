@@ -18,30 +18,11 @@ import subprocess
 import sys
 from typing import List, Optional, Sequence
 
+# Ranks get 8 hardware queues (a rank drives more HIP streams -- training, weight gradients, re-pack, sampler,
+# gradient buckets + RCCL's own -- than ROCm's default 4, and streams that alias one queue execute in order);
+# segmantic_amd/__init__.py sets the same for any process that is imported with WORLD_SIZE > 1.
 HW_QUEUES_ENV = "GPU_MAX_HW_QUEUES"
 HW_QUEUES_DEFAULT = "8"
-
-
-def set_runtime_env() -> bool:
-    """Environment the HIP runtime reads when it initialises (first device call of the process).
-
-    ``GPU_MAX_HW_QUEUES``: a rank drives more HIP streams (training, weight gradients, residual
-    branch, sampler / prefetch, two inference lanes, gradient buckets + RCCL's own) than ROCm's
-    default 4 hardware queues; streams that alias one queue execute in order, which serialises work
-    that was put on separate streams to overlap (measured: 6.4 vs 5.9 ms per fit step with a fifth
-    stream, round 2).  Set for multi-rank processes only (single-GPU runs measured 0.5-5 % slower with 8
-    queues, segmantic_amd/__init__.py).  An exported value wins.  Returns False when the runtime was already
-    initialised in this process (the setting then has no effect and the caller may want to say so)."""
-    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-        os.environ.setdefault(HW_QUEUES_ENV, HW_QUEUES_DEFAULT)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch = sys.modules.get("torch")
-    if torch is None:
-        return True
-    try:
-        return not torch.cuda.is_initialized()
-    except Exception:       # pragma: no cover
-        return True
 
 
 def under_launcher() -> bool:

@@ -186,9 +186,17 @@ class Net(torch.nn.Module):
         if (self.training or out_ndhwc.dtype != eng.dtype or not out_ndhwc.is_contiguous()
                 or eng.kpad != eng.net.out_channels):
             return False
+        if isinstance(x, ops.WindowBatch) and not eng.window_views_ok(x.dtype):
+            return False
         with torch.cuda.device(eng.device):
             eng.forward(x, train=False, out=out_ndhwc, lane=lane)
         return True
+
+    def window_views_ok(self, dtype) -> bool:
+        """sliding-window driver: may it hand ``forward_into`` an ``ops.WindowBatch`` (windows read in place)?"""
+        if self.training or self.device.type != "cuda":
+            return False
+        return self._engine_for().window_views_ok(dtype)
 
     # ------------------------------------------------------------------ optimisers
     def configure_optimizers(self):

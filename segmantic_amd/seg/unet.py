@@ -888,6 +888,8 @@ class UNetEngine:
         if ru["res"] is not None:
             rc = ru["res"]
             paired = self._pair_ok(ru, x, out, f"{pre}.ea0", (n, d, h, w))
+            if isinstance(x, ops.WindowBatch) and not paired:
+                raise RuntimeError("window views need the first-layer pair kernel (window_views_ok said yes?)")
             merged = None if paired else self._merged_eval(ru, x, (n, d, h, w))
             if not paired and merged is None:
                 br = self._fork_branch()
@@ -1030,6 +1032,15 @@ class UNetEngine:
     def _prep_input(self, x: torch.Tensor) -> torch.Tensor:
         """x: [N, C, D, H, W] float32 (reference layout; [N, C, H, W] or depth 1 for a 2-D
         network) -> NDHWC compute-dtype tensor."""
+        if isinstance(x, ops.WindowBatch):      # sliding windows read in place by the first-layer kernel
+            if not self.window_views_ok(x.dtype):
+                raise ValueError("this network / precision cannot read window views (ask window_views_ok)")
+            total_stride = 1
+            for s in self.net.strides[:len(self.net.channels) - 1]:
+                total_stride *= s
+            if any(r % total_stride for r in x.roi):
+                raise ValueError(f"window extent {x.roi} is not divisible by the network's total stride {total_stride}")
+            return x
         if self.net.dimensions == 2 and x.dim() == 4:
             x = x.unsqueeze(2)
         if x.dim() != 5 or x.shape[1] != self.net.in_channels or (self.net.dimensions == 2 and x.shape[2] != 1):
@@ -1056,6 +1067,20 @@ class UNetEngine:
             return xin
         ops.nchw_to_ndhwc(x.float().contiguous(), xin)
         return xin
+
+    def window_views_ok(self, dtype) -> bool:
+        """inference: the first residual unit can read its windows straight from the volume
+        (``ops.WindowBatch`` -> ``segmi_windows``): single input channel, 3-D, the small-Cin pair kernel
+        (subunit 0 + residual convolution in one launch) takes the unit, windows in the compute dtype"""
+        ru = self.levels["down"]
+        units, rc = ru["units"], ru["res"]
+        if self.net.in_channels != 1 or self.net.dimensions != 3 or dtype != self.dtype:
+            return False
+        if len(units) < 2 or units[0][1] is None or rc is None:
+            return False
+        c0 = units[0][0]
+        return (not c0.mfma and not rc.mfma and c0.k == 3 and rc.k == 3 and c0.stride == rc.stride
+                and c0.cout == rc.cout and c0.cout in (16, 32))
 
     def forward(self, x: torch.Tensor, train: Optional[bool] = None,
                 out: Optional[torch.Tensor] = None, lane: int = 0) -> torch.Tensor:

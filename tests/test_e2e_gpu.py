@@ -906,3 +906,34 @@ def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch)
         assert torch.equal(w0, w), (defer, depth, carry)
         assert all(torch.equal(sd0[k], sd[k]) for k in sd0), (defer, depth, carry)
         assert torch.equal(y0, y), (defer, depth, carry)
+
+
+@pytest.mark.parametrize("vol,roi,overlap", [((96, 96, 96), 32, 0.5), ((72, 80, 88), 32, 0.25), ((64, 64, 70), 32, 0.5)])
+def test_windows_read_in_place_equal_gathered_windows(vol, roi, overlap, monkeypatch):
+    """sliding-window driver, own network: the first-layer kernel reads the windows as views of the volume
+    (ops.WindowBatch / segmi_windows) instead of a gathered batch.  Same bits; volumes whose rows are not
+    4-element aligned (W = 70) silently keep the gather."""
+    from segmantic_amd import ops
+    _, net = pair(16, (16, 32, 64), (2, 2))
+    net.eval()
+    net.mixed_precision = True
+    g = torch.Generator().manual_seed(21)
+    img = torch.randn((1, 1) + vol, generator=g).to(DEV)
+    calls = {"views": 0}
+    real = ops.WindowBatch.windows
+
+    def counting(self):
+        calls["views"] += 1
+        return real(self)
+    monkeypatch.setattr(ops.WindowBatch, "windows", counting)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SEGMI_SW_VIEWS", flag)
+        with torch.no_grad():
+            r = sliding_window_inference(img, (roi,) * 3, 4, net, overlap, return_labels=True)
+        torch.cuda.synchronize()
+        outs[flag] = (r.logits.clone(), r.labels.clone())
+        if flag == "0":
+            assert calls["views"] == 0
+    assert (calls["views"] > 0) == (vol[2] % 4 == 0)
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
