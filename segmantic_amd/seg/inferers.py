@@ -105,6 +105,16 @@ def _lane_streams(device, n: Optional[int] = None):
     return _LANES[key]
 
 
+_BLEND_STREAMS: dict = {}
+
+
+def _blend_stream(device):
+    key = torch.device(device).index
+    if key not in _BLEND_STREAMS:
+        _BLEND_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _BLEND_STREAMS[key]
+
+
 def group_factor() -> int:
     """sw_batch_size multiplier for window groups handed to this build's own network
     (SEGMI_SW_GROUP, default 4: 18.4 -> 20.8 volumes/s on the 512^3 benchmark; 2 -> 19.9)"""
@@ -237,6 +247,47 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         main = torch.cuda.current_stream(dev)
         forked = False
         volc = img[b].reshape(orig).to(window_dtype) if views_ok else None
+        # Pipelined blend (own network, one lane, whole volume): the windows run z-level by z-level, so once
+        # the last window of z-level k is done every output plane below the next level's origin is final --
+        # that slab is blended (same kernel, same ordered sums: bit-identical) on a second stream while the
+        # forwards of the following levels run.  The blend is HBM-bound, the forwards are issue-bound: of the
+        # 6.1 ms the one-shot blend of a 512^3 volume takes, only the last slab's share stays exposed.
+        pipe = (into is not None and lanes is None and not partial and z_slab is None
+                and len(per_dim[0]) >= 2 and os.environ.get("SEGMI_SW_PIPE_BLEND", "1") != "0")
+        nyx = len(per_dim[1]) * len(per_dim[2])
+        z_done, next_level = 0, 0
+        lab_p = acc_p = cnt_p = None
+        def blend_finished_levels(last_window):
+            """blend every slab whose covering windows are all enqueued (windows <= last_window)"""
+            nonlocal z_done, next_level, lab_p, acc_p, cnt_p
+            if not (pipe and deferred and cache is not None):
+                return
+            nz = len(per_dim_u[0])
+            while next_level < nz and last_window >= (next_level + 1) * nyx - 1:
+                z1 = per_dim_u[0][next_level + 1] if next_level + 1 < nz else orig[0]
+                z1 = max(0, min(int(z1), orig[0]))
+                next_level += 1
+                if z1 <= z_done:
+                    continue
+                if cnt_p is None:
+                    cnt_p = torch.empty((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
+                    if want_logits:
+                        acc_p = torch.empty((1, orig[0], orig[1], orig[2], K), dtype=torch.float32, device=dev)
+                    if return_labels:
+                        lab_p = torch.empty((orig[0], orig[1], orig[2]),
+                                            dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)
+                bs = _blend_stream(dev)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                bs.wait_event(ev)
+                with torch.cuda.stream(bs):
+                    ops.sw_blend(cache, [[s0 - z_done for s0 in per_dim_u[0]], per_dim_u[1], per_dim_u[2]], lo, hi,
+                                 roi, z1 - z_done, orig[1], orig[2], importance=imp,
+                                 out_logits=acc_p[:, z_done:z1] if acc_p is not None else None,
+                                 out_count=cnt_p[z_done:z1], labels=lab_p[z_done:z1] if lab_p is not None else None,
+                                 normalize=True)
+                z_done = z1
+
         for gi, g0 in enumerate(range(lo, hi, sw_batch_size)):
             grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
             slot = g0 - lo
@@ -278,6 +329,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     lane_events[0].append((e0, e1))
+                blend_finished_levels(g0 + len(grp) - 1)
                 continue                                   # windows read in place, predicted straight into the cache
             wbuf = torch.empty((len(grp), roi[0], roi[1], roi[2], Cin), dtype=window_dtype,
                                device=dev)
@@ -288,6 +340,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     lane_events[0].append((e0, e1))
+                blend_finished_levels(g0 + len(grp) - 1)
                 continue                                   # predicted straight into the cache
             pn = as_ndhwc(predictor(wview))
             if K is None:                                  # first group: pick the strategy
@@ -304,6 +357,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                     cnt = torch.zeros((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
             if deferred:
                 cache[slot:slot + len(grp)].copy_(pn)
+                blend_finished_levels(g0 + len(grp) - 1)
             else:
                 ops.sw_scatter_add(pn, grp, acc, cnt, imp)
         if forked:
@@ -319,6 +373,15 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
             t_enq = _time.perf_counter()
             lane_events = [[] for _ in lane_events]
         lab = None
+        if cnt_p is not None:
+            # slabs were blended on the way; whatever is left (nothing, when the last level ended the loop)
+            blend_finished_levels(hi - 1)
+            assert z_done == orig[0], (z_done, orig[0])
+            main.wait_stream(_blend_stream(dev))
+            acc, cnt, lab = acc_p, cnt_p, lab_p
+            cache = None
+            outs.append(acc); cnts.append(cnt); labs.append(lab if return_labels else None)
+            continue
         if not partial and return_labels:
             lab = torch.empty((out_d, orig[1], orig[2]),
                               dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)

@@ -937,3 +937,29 @@ def test_windows_read_in_place_equal_gathered_windows(vol, roi, overlap, monkeyp
             assert calls["views"] == 0
     assert (calls["views"] > 0) == (vol[2] % 4 == 0)
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+
+
+@pytest.mark.parametrize("vol,roi,overlap,mode", [((96, 96, 96), 32, 0.5, "constant"), ((72, 80, 88), 32, 0.25, "gaussian"),
+                                                   ((40, 64, 64), 32, 0.5, "constant"), ((32, 48, 48), 32, 0.5, "constant")])
+def test_pipelined_slab_blend_is_bit_identical(vol, roi, overlap, mode, monkeypatch):
+    """The deferred blend runs slab by slab on a second stream as the z-levels of windows complete (round 3);
+    logits, labels and the count map are those of the one-shot blend, bit for bit (same kernel, same ordered
+    sums), also when the volume has a single z-level (nothing to pipeline)."""
+    _, net = pair(16, (16, 32, 64), (2, 2))
+    net.eval()
+    net.mixed_precision = True
+    g = torch.Generator().manual_seed(33)
+    img = torch.randn((2, 1) + vol, generator=g).to(DEV)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SEGMI_SW_PIPE_BLEND", flag)
+        with torch.no_grad():
+            r = sliding_window_inference(img, (roi,) * 3, 4, net, overlap, mode=mode, return_labels=True)
+            l = sliding_window_inference(img, (roi,) * 3, 4, net, overlap, mode=mode, return_labels=True,
+                                         return_logits=False)
+        torch.cuda.synchronize()
+        outs[flag] = (r.logits.clone(), r.labels.clone(), r.count.clone(), l.labels.clone())
+        assert l.logits is None
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs["1"][1], outs["1"][3])
