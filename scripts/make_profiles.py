@@ -31,8 +31,12 @@ for wl, name in (("train", "train_b8_128_bf16"), ("infer", "infer_512_bf16")):
     st = newest(f"{wl}_stats/*/*kernel_stats.csv")
     shutil.copy(st, os.path.join(OUT, f"{tag}_{name}_kernel_stats.csv"))
     steps = "13"
-    if wl == "infer":      # volumes of the run = launches of the blend kernel (the warm-up is adaptive since round 3)
-        steps = str(sum(int(r["Calls"]) for r in csv.DictReader(open(st)) if "sw_blend_kernel" in r["Name"]))
+    if wl == "infer":
+        # volumes of the run (the warm-up is adaptive since round 3) = launches of the fused decoder top / 22 window
+        # groups per 512^3 volume (343 windows in groups of 16); the blend runs as 7 z-slab launches per volume
+        calls = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(st))}
+        dt = sum(v for k, v in calls.items() if "dectop_kernel" in k)
+        steps = str(dt // 22 if dt and dt % 22 == 0 else sum(v for k, v in calls.items() if "sw_blend_kernel" in k))
     open(os.path.join(OUT, f"{tag}_{name}_kernel_stats.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload infer --steps 2 --warmup 1' if wl == 'infer' else '--workload train --steps 10 --warmup 3'} --no-cpu-baseline\n"
         f"# ({'both streams overlapped' if wl == 'train' else 'one lane (the default)'}; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
