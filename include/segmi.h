@@ -283,6 +283,18 @@ int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
                            const segmi_act* dx, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const float* prelu_alpha,
                            const float* coef, float dropout_p, uint32_t dropout_seed, void* stream);
+/* segmi_bn_act_bwd_apply fused into the k3 stride-2 convolution that consumes its result -- the input gradient
+ * of a decoder level's ConvTranspose3d (monai UNet up layer, monai_unet.py:114-124; backward of :345): the
+ * convolution computes dx = apply(dy, x) while it stages its halo tile, feeds the bf16-rounded values to its
+ * MFMAs and writes dx once (for the weight gradient): same bits as the two calls, one pass over dx less.
+ * bf16, 16 channels, out->c in {16, 32, 64}, out->w >= 16, no dropout; `packed`: segmi_wpack of the
+ * convolution (kind 0, as segmi_conv3d_fwd takes it).  dx must not alias dy or x. */
+int segmi_bn_act_bwd_apply_conv_ok(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
+                                   const segmi_act* out);
+int segmi_bn_act_bwd_apply_conv(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const float* prelu_alpha, const float* coef, const segmi_act* out,
+                                const void* packed, void* stream);
 
 /* elementwise helpers on NDHWC views */
 int segmi_add(int dtype, const segmi_act* a, const segmi_act* b, const segmi_act* out,

@@ -121,6 +121,8 @@ SIGNATURES = {
     "segmi_bn_act_bwd_fused_rows": (_i, [_AP]),
     "segmi_bn_act_bwd_fused": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwdFin), _P]),
     "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
+    "segmi_bn_act_bwd_apply_conv_ok": (_i, [_i, _AP, _AP, _AP, _AP]),
+    "segmi_bn_act_bwd_apply_conv": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _AP, _P, _P]),
     "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),
     "segmi_cast_copy": (_i, [_i, _AP, _i, _AP, _P]),
     "segmi_nchw_to_ndhwc": (_i, [_P, _i, _AP, _P]),

@@ -124,6 +124,57 @@ template <typename V> __device__ __forceinline__ void touch_v(V& v) { asm volati
 // scalar variant for wave-uniform values; "+v" because hipcc may already hold them in a VGPR
 __device__ __forceinline__ void touch_s(float& v) { asm volatile("" : "+v"(v)); }
 
+// One element of the BatchNorm (+ PReLU) backward apply, dx = gamma*invstd*(dz - c0 - xhat*c1), shared by
+// bn_act_bwd_apply_kernel, the one-launch variant for small tensors and the stride-2 convolution that
+// applies it while staging (conv_bnbwd_impl.h).  Contraction is spelled out (one fma, chosen here, not by
+// the optimiser per call site): the three kernels must produce the same bits.  m: dropout multiplier (1 = none).
+__device__ __forceinline__ float bn_bwd_apply_elem(float a, float d, float mean, float is, float gm, float beta,
+                                                   float c0, float c1, bool has_alpha, float alpha, float m) {
+#pragma clang fp contract(off)
+  const float xh = (a - mean) * is;
+  const float z = fmaf(xh, gm, beta) * m;
+  float dz = d;
+  if (has_alpha && !(z > 0.f)) dz = alpha * d;
+  dz *= m;
+  return (gm * is) * fmaf(-xh, c1, dz - c0);
+}
+
+// Two elements at once, no dropout: the same operations in the same order as bn_bwd_apply_elem with m = 1
+// (x * 1 is exact), written on 2-vectors so that hipcc emits the packed f32 forms (v_pk_add / v_pk_mul /
+// v_pk_fma_f32: two lanes' worth of IEEE results per issue).  These passes are VALU-bound, not memory-bound:
+// ~15 scalar operations per element put the full-resolution apply at 205 us of vector issue out of its 306.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool HAS_ALPHA>
+__device__ __forceinline__ f32x2 bn_bwd_apply_elem2(f32x2 a, f32x2 d, f32x2 mean, f32x2 is, f32x2 gm, f32x2 beta,
+                                                    f32x2 c0, f32x2 c1, float alpha) {
+#pragma clang fp contract(off)
+  const f32x2 xh = (a - mean) * is;
+  f32x2 dz = d;
+  if constexpr (HAS_ALPHA) {
+    const f32x2 z = __builtin_elementwise_fma(xh, gm, beta);
+    const f32x2 ad = alpha * d;
+    dz[0] = !(z[0] > 0.f) ? ad[0] : d[0];
+    dz[1] = !(z[1] > 0.f) ? ad[1] : d[1];
+  }
+  return (gm * is) * __builtin_elementwise_fma(-xh, c1, dz - c0);
+}
+
+// the same with gamma * invstd supplied by the caller (a per-channel constant it keeps in registers)
+template <bool HAS_ALPHA>
+__device__ __forceinline__ f32x2 bn_bwd_apply_elem2g(f32x2 a, f32x2 d, f32x2 mean, f32x2 is, f32x2 gm, f32x2 beta,
+                                                     f32x2 c0, f32x2 c1, f32x2 gm_is, float alpha) {
+#pragma clang fp contract(off)
+  const f32x2 xh = (a - mean) * is;
+  f32x2 dz = d;
+  if constexpr (HAS_ALPHA) {
+    const f32x2 z = __builtin_elementwise_fma(xh, gm, beta);
+    const f32x2 ad = alpha * d;
+    dz[0] = !(z[0] > 0.f) ? ad[0] : d[0];
+    dz[1] = !(z[1] > 0.f) ? ad[1] : d[1];
+  }
+  return gm_is * __builtin_elementwise_fma(-xh, c1, dz - c0);
+}
+
 // BatchNorm-apply + PReLU of the PRODUCER layer on 8 bf16 channels of one voxel, done while the
 // consumer stages its input (segmi_in_affine): z = fma(x, scale, shift); z = z > 0 ? z : alpha * z,
 // rounded to bf16 exactly as bn_act_fwd stores it, so a consumer that transforms on the fly sees

@@ -5,8 +5,11 @@
 #include "conv_ring_impl.h"
 #include "conv_ks_impl.h"
 #include "convt_ps_impl.h"
+#include "conv_bnbwd_impl.h"
 
 namespace segmi {
+
+int conv_s2_bnbwd_bf16(const ConvBnBwdParams& p, hipStream_t st);
 
 int conv_mfma_f32(const ConvParams& p, int ksize, int stride, hipStream_t st);
 int conv_mfma_bf16(const ConvParams& p, int ksize, int stride, hipStream_t st);
@@ -262,6 +265,43 @@ int segmi_conv3d_bn_bwd_sums_ok(int dtype, const segmi_act* in, const segmi_act*
   // the ring kernel's 16-channel single-tile variant (conv_ring2_kernel<bf16, 16, 1, MODE 4>)
   return in->c == 16 && out->c == 16 && ksize == 3 && stride == 1 &&
                  conv_ring_ok(dtype, in->c, ksize, stride, out) ? 1 : 0;
+}
+
+int segmi_bn_act_bwd_apply_conv_ok(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
+                                   const segmi_act* out) {
+  if (dtype != SEGMI_BF16 || !act_ok(dy) || !act_ok(x) || !act_ok(dx) || !act_ok(out)) return 0;
+  const segmi_act* a3[3] = {dy, x, dx};
+  for (const segmi_act* a : a3) {
+    if (a->n != dy->n || a->d != dy->d || a->h != dy->h || a->w != dy->w || a->c != 16) return 0;
+    if (a->ld % 8 != 0 || ((uintptr_t)a->data % 16) != 0) return 0;
+  }
+  if (out->n != dy->n || out->d != out_extent(dy->d, 3, 2) || out->h != out_extent(dy->h, 3, 2) ||
+      out->w != out_extent(dy->w, 3, 2))
+    return 0;
+  if (!(out->c == 16 || out->c == 32 || out->c == 64) || out->ld % 4 != 0 || ((uintptr_t)out->data % 8) != 0)
+    return 0;
+  // 32-bit byte offsets inside one sample of dy / x / dx
+  const int64_t vox = (int64_t)dy->d * dy->h * dy->w;
+  if (vox * dy->ld * 2 >= (1ll << 31) || vox * x->ld * 2 >= (1ll << 31) || vox * dx->ld * 2 >= (1ll << 31)) return 0;
+  // the 2 x 4 x 16 output tile of the wide stride-2 configuration
+  return out->w >= 16 ? 1 : 0;
+}
+
+int segmi_bn_act_bwd_apply_conv(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const float* prelu_alpha, const float* coef, const segmi_act* out,
+                                const void* packed, void* stream) {
+  SEGMI_CHECK_ARG(segmi_bn_act_bwd_apply_conv_ok(dtype, dy, x, dx, out) && mean && invstd && coef && packed,
+                  "bn_act_bwd_apply_conv: not eligible (ask segmi_bn_act_bwd_apply_conv_ok) or bad arguments");
+  SEGMI_CHECK_ARG(dx->data != dy->data && dx->data != x->data,
+                  "bn_act_bwd_apply_conv: dx must not alias dy or x (halo voxels are re-read by neighbouring tiles)");
+  ConvBnBwdParams p{};
+  p.dy = dy->data; p.x = x->data; p.dx = dx->data; p.out = out->data; p.wfrag = packed;
+  p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = prelu_alpha; p.coef = coef;
+  p.N = dy->n; p.Di = dy->d; p.Hi = dy->h; p.Wi = dy->w; p.Do = out->d; p.Ho = out->h; p.Wo = out->w;
+  p.Cout = out->c; p.ldy = dy->ld; p.ldx = x->ld; p.lddx = dx->ld; p.ldo = out->ld;
+  p.ntiles_total = out->c / 16;
+  return conv_s2_bnbwd_bf16(p, (hipStream_t)stream);
 }
 
 int segmi_conv3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,

@@ -302,20 +302,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(EwParams p) {
     float a[VEC], d[VEC];
     loadv<T, VEC>(x + v * p.ldx + ch, a);
     loadv<T, VEC>(dy + v * p.ldy + ch, d);
+    if (VEC % 2 == 0 && !p.drop_thresh) {        // the common case, on packed f32 operations (same bits)
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      const float is = prm[p.c + ch + k], gm = prm[2 * p.c + ch + k];
-      const float xh = (a[k] - prm[ch + k]) * is;
-      float z = fmaf(xh, gm, prm[3 * p.c + ch + k]);
-      float m = 1.f;
-      if (p.drop_thresh) {
-        m = drop_mult(p.drop_seed, v * p.c + ch + k, p.drop_thresh, p.drop_scale);
-        z *= m;
+      for (int k = 0; k + 1 < VEC; k += 2) {
+        const float* q = prm + ch + k;
+        const f32x2 a2{a[k], a[k + 1]}, d2{d[k], d[k + 1]};
+        const f32x2 m2{q[0], q[1]}, i2{q[p.c], q[p.c + 1]}, g2{q[2 * p.c], q[2 * p.c + 1]},
+            b2{q[3 * p.c], q[3 * p.c + 1]}, c02{q[4 * p.c], q[4 * p.c + 1]}, c12{q[5 * p.c], q[5 * p.c + 1]};
+        const f32x2 o2 = has_alpha ? bn_bwd_apply_elem2<true>(a2, d2, m2, i2, g2, b2, c02, c12, alpha)
+                                   : bn_bwd_apply_elem2<false>(a2, d2, m2, i2, g2, b2, c02, c12, alpha);
+        a[k] = o2[0]; a[k + 1] = o2[1];
       }
-      float dz = d[k];
-      if (has_alpha && !(z > 0.f)) dz = alpha * d[k];
-      dz *= m;
-      a[k] = gm * is * (dz - prm[4 * p.c + ch + k] - xh * prm[5 * p.c + ch + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float m = 1.f;
+        if (p.drop_thresh) m = drop_mult(p.drop_seed, v * p.c + ch + k, p.drop_thresh, p.drop_scale);
+        a[k] = bn_bwd_apply_elem(a[k], d[k], prm[ch + k], prm[p.c + ch + k], prm[2 * p.c + ch + k],
+                                 prm[3 * p.c + ch + k], prm[4 * p.c + ch + k], prm[5 * p.c + ch + k], has_alpha,
+                                 alpha, m);
+      }
     }
     storev<T, VEC>(o + v * p.ldo + ch, a);
   }
@@ -364,14 +370,23 @@ struct BnBwdFinPub {            // BnBwdFin whose coef stores are visible to the
   }
 };
 
+// Shape of the launch (round 3, second cut): 1024 threads per workgroup and 4 voxels per thread in flight.
+// The first cut ran 256 threads with one 8-byte load per tensor in flight: one wave per SIMD, 1 KB per wave
+// and round trip -- 31 us for the 50 MB of a 32^3 x 32-channel layer (1.6 TB/s), pure load latency on the
+// dependent chain of the step.
+constexpr int kFusedThreads = 1024;
+constexpr int kFusedU = 4;
+
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(EwParams p) {
-  constexpr int VEC = 4;
-  extern __shared__ double fused_lds[];          // fin tail: (3c + 1024) doubles; afterwards [6][c] floats
-  __shared__ float red[256 * 3 * VEC];
+__global__ __launch_bounds__(kFusedThreads) void bn_act_bwd_fused_kernel(EwParams p) {
+  constexpr int VEC = 4, NTH = kFusedThreads, U = kFusedU;
+  // dynamic LDS, three uses one after the other: per-workgroup fold of the partial sums
+  // ([slots][3][VEC] + [4][3c] floats), fin tail ((3c + 4 NTH) doubles), then [2][c] floats (c0, c1)
+  extern __shared__ double fused_lds[];
   __shared__ int s_ok;
   const int cg = p.c / VEC;
-  const int vpp = 256 / cg > 0 ? 256 / cg : 1;
+  const int vpp = NTH / cg;                      // voxels per pass of the workgroup
+  const int vq = (vpp + 3) / 4;                  // ... per quarter of it (the fold runs quarter by quarter)
   const int tid = threadIdx.x;
   const int my_cg = tid % cg, my_v = tid / cg;
   const int64_t v0 = (int64_t)blockIdx.x * p.vpw;
@@ -396,38 +411,67 @@ __global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(EwParams p) {
 #pragma unroll
   for (int k = 0; k < VEC; ++k) s0[k] = s1[k] = s2[k] = 0.f;
   if (ok) {
-    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
-      float a[VEC], d[VEC];
-      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
-      loadv<T, VEC>(dy + v * p.ldy + my_cg * VEC, d);
+    for (int64_t v = v0 + my_v; v < v1; v += (int64_t)U * vpp) {
+      float a[U][VEC], d[U][VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const float xh = (a[k] - mean[k]) * istd[k];
-        const float z = fmaf(xh, gam[k], bet[k]);
-        float dz = d[k];
-        if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[k], z, s2[k]); dz = alpha * d[k]; }
-        s0[k] += dz;
-        s1[k] = fmaf(dz, xh, s1[k]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t vu = v + (int64_t)u * vpp < v1 ? v + (int64_t)u * vpp : v;   // tail: a harmless re-read
+        loadv<T, VEC>(x + vu * p.ldx + my_cg * VEC, a[u]);
+        loadv<T, VEC>(dy + vu * p.ldy + my_cg * VEC, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v + (int64_t)u * vpp < v1) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float xh = (a[u][k] - mean[k]) * istd[k];
+            const float z = fmaf(xh, gam[k], bet[k]);
+            float dz = d[u][k];
+            if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[u][k], z, s2[k]); dz = alpha * d[u][k]; }
+            s0[k] += dz;
+            s1[k] = fmaf(dz, xh, s1[k]);
+          }
+        }
       }
     }
   }
+  // fold over the workgroup, fixed order: the four quarters of the voxel lanes one after the other into
+  // red[slot][3][VEC], then the slots of each channel in four sub-ranges, then those four
+  float* red = reinterpret_cast<float*>(fused_lds);
+  float* red2 = red + vq * cg * 3 * VEC;                        // [4][3c]
+  {
+    const int q = my_v / vq, slot = (my_v - q * vq) * cg + my_cg;
+    for (int q4 = 0; q4 < 4; ++q4) {
+      if (ok && q == q4) {
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    red[tid * 3 * VEC + k] = s0[k];
-    red[tid * 3 * VEC + VEC + k] = s1[k];
-    red[tid * 3 * VEC + 2 * VEC + k] = s2[k];
+        for (int k = 0; k < VEC; ++k) {
+          float* r3 = red + slot * 3 * VEC + k;
+          if (q4 == 0) { r3[0] = s0[k]; r3[VEC] = s1[k]; r3[2 * VEC] = s2[k]; }
+          else { r3[0] += s0[k]; r3[VEC] += s1[k]; r3[2 * VEC] += s2[k]; }
+        }
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  for (int q = tid; q < 3 * p.c; q += 256) {
+  const int vs = (vq + 3) / 4;
+  for (int e = tid; e < 4 * 3 * p.c; e += NTH) {
+    const int sub = e / (3 * p.c), q = e - sub * 3 * p.c;
     const int which = q / p.c, ch = q % p.c;
     const int g = ch / VEC, k = ch % VEC;
+    const int va = sub * vs, vb = va + vs < vq ? va + vs : vq;
     float acc = 0.f;
-    for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 3 * VEC + which * VEC + k];
-    fin_store(&p.out_partials[((int64_t)blockIdx.x * 3 + which) * p.c + ch], acc);
+    for (int v = va; v < vb; ++v) acc += red[(v * cg + g) * 3 * VEC + which * VEC + k];
+    red2[e] = acc;
   }
+  __syncthreads();
+  for (int q = tid; q < 3 * p.c; q += NTH) {
+    const float acc = (red2[q] + red2[3 * p.c + q]) + (red2[2 * 3 * p.c + q] + red2[3 * 3 * p.c + q]);
+    fin_store(&p.out_partials[(int64_t)blockIdx.x * 3 * p.c + q], acc);
+  }
+  __syncthreads();                               // red / red2 are dead: the tail reuses the LDS
   // ---- finalisation by the last workgroup, then the hand-off
   const FinTail ft = kernarg_late<FinTail>(offsetof(EwParams, ft));
-  const bool last = fin_tail_run<BnBwdFinPub, 256, offsetof(EwParams, ft), offsetof(EwParams, bbfin)>(p.out_partials, fused_lds);
+  const bool last = fin_tail_run<BnBwdFinPub, NTH, offsetof(EwParams, ft), offsetof(EwParams, bbfin)>(p.out_partials, fused_lds);
   if (last) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this thread's coef stores have completed
     __syncthreads();
@@ -437,34 +481,44 @@ __global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(EwParams p) {
     int good = 1;
     unsigned spins = 0;
     while (__hip_atomic_load(&g_fused_flags[ft.ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-      __builtin_amdgcn_s_sleep(16);
-      if (++spins > (1u << 23)) { good = 0; atomicAdd(&g_fused_timeouts, 1u); break; }
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 24)) { good = 0; atomicAdd(&g_fused_timeouts, 1u); break; }
     }
     s_ok = good;
   }
   __syncthreads();
   const float poison = s_ok ? 0.f : __builtin_nanf("");
   float* prm = reinterpret_cast<float*>(fused_lds);            // [2][c]: c0, c1
-  for (int i = tid; i < 2 * p.c; i += 256) prm[i] = fin_load1(p.coef + i) + poison;
+  for (int i = tid; i < 2 * p.c; i += NTH) prm[i] = fin_load1(p.coef + i) + poison;
   __syncthreads();
   // ---- pass 2: dx = gamma*invstd*(dz - c0 - xhat*c1) over the same range (as bn_act_bwd_apply_kernel)
   if (ok) {
     float c0[VEC], c1[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { c0[k] = prm[my_cg * VEC + k]; c1[k] = prm[p.c + my_cg * VEC + k]; }
-    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
-      float a[VEC], d[VEC];
-      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
-      loadv<T, VEC>(dy + v * p.ldy + my_cg * VEC, d);
+    for (int64_t v = v0 + my_v; v < v1; v += (int64_t)U * vpp) {
+      float a[U][VEC], d[U][VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const float xh = (a[k] - mean[k]) * istd[k];
-        const float z = fmaf(xh, gam[k], bet[k]);
-        float dz = d[k];
-        if (has_alpha && !(z > 0.f)) dz = alpha * d[k];
-        a[k] = gam[k] * istd[k] * (dz - c0[k] - xh * c1[k]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t vu = v + (int64_t)u * vpp < v1 ? v + (int64_t)u * vpp : v;
+        loadv<T, VEC>(x + vu * p.ldx + my_cg * VEC, a[u]);
+        loadv<T, VEC>(dy + vu * p.ldy + my_cg * VEC, d[u]);
       }
-      storev<T, VEC>(o + v * p.ldo + my_cg * VEC, a);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v + (int64_t)u * vpp < v1) {
+#pragma unroll
+          for (int k = 0; k < VEC; k += 2) {
+            const f32x2 a2{a[u][k], a[u][k + 1]}, d2{d[u][k], d[u][k + 1]};
+            const f32x2 m2{mean[k], mean[k + 1]}, i2{istd[k], istd[k + 1]}, g2{gam[k], gam[k + 1]},
+                b2{bet[k], bet[k + 1]}, c02{c0[k], c0[k + 1]}, c12{c1[k], c1[k + 1]};
+            const f32x2 o2 = has_alpha ? bn_bwd_apply_elem2<true>(a2, d2, m2, i2, g2, b2, c02, c12, alpha)
+                                       : bn_bwd_apply_elem2<false>(a2, d2, m2, i2, g2, b2, c02, c12, alpha);
+            a[u][k] = o2[0]; a[u][k + 1] = o2[1];
+          }
+          storev<T, VEC>(o + (v + (int64_t)u * vpp) * p.ldo + my_cg * VEC, a[u]);
+        }
+      }
     }
   }
 }
@@ -688,13 +742,14 @@ int segmi_bn_act_bwd_fused(int dtype, const segmi_act* dy, const segmi_act* x, c
   const int rows = (int)cdiv64(p.nvox, p.vpw);
   p.fin_on = 1;
   p.bbfin = BnBwdFin{x->c, fin->count, fin->dgamma, fin->dbeta, fin->dalpha, fin->coef};
-  size_t lds = fin_tail_arm(p, dim3((unsigned)rows), 256, 3 * x->c, 0);
-  if (lds < 2 * (size_t)x->c * sizeof(float)) lds = 2 * (size_t)x->c * sizeof(float);
+  const int cg4 = x->c / 4, vq = (kFusedThreads / cg4 + 3) / 4;
+  const size_t fold = ((size_t)vq * cg4 * 12 + 12 * (size_t)x->c) * sizeof(float);   // the kernel's red + red2
+  const size_t lds = fin_tail_arm(p, dim3((unsigned)rows), kFusedThreads, 3 * x->c, fold);
   p.epoch = g_fused_epoch.fetch_add(1);
   if (p.epoch == 0) p.epoch = g_fused_epoch.fetch_add(1);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SEGMI_F32) hipLaunchKernelGGL(bn_act_bwd_fused_kernel<float>, rows, 256, lds, st, p);
-  else hipLaunchKernelGGL(bn_act_bwd_fused_kernel<bf16_t>, rows, 256, lds, st, p);
+  if (dtype == SEGMI_F32) hipLaunchKernelGGL(bn_act_bwd_fused_kernel<float>, rows, kFusedThreads, lds, st, p);
+  else hipLaunchKernelGGL(bn_act_bwd_fused_kernel<bf16_t>, rows, kFusedThreads, lds, st, p);
   SEGMI_LAUNCH_CHECK("bn_act_bwd_fused");
   return SEGMI_OK;
 }

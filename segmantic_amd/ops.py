@@ -399,6 +399,21 @@ def bn_act_bwd_fused(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, partials
                                      C.byref(bf), _stream()), "bn_act_bwd_fused")
 
 
+def bn_act_bwd_apply_conv_ok(dy, x, dx, out) -> bool:
+    ady, ax, adx, ao = act(dy), act(x), act(dx), act(out)
+    return bool(lib.segmi_bn_act_bwd_apply_conv_ok(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx),
+                                                   C.byref(ao)))
+
+
+def bn_act_bwd_apply_conv(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, coef, out, packed) -> None:
+    """dx = bn_act_bwd_apply(dy, x) and out = conv_k3s2(dx) as ONE launch (the input gradient of a decoder
+    level's transposed convolution; csrc/conv_bnbwd_impl.h): same bits as the two calls"""
+    ady, ax, adx, ao = act(dy), act(x), act(dx), act(out)
+    check(lib.segmi_bn_act_bwd_apply_conv(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx), _ptr(mean),
+                                          _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(prelu_alpha), _ptr(coef),
+                                          C.byref(ao), _ptr(packed), _stream()), "bn_act_bwd_apply_conv")
+
+
 def bn_act_bwd_finalize(partials, rows, c, count, gamma, invstd, dgamma, dbeta, dalpha,
                         coef) -> None:
     check(lib.segmi_bn_act_bwd_finalize(_ptr(partials), rows, c, float(count), _ptr(gamma),

@@ -716,9 +716,16 @@ class UNetEngine:
         count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
         return (count, bn.g_gamma, bn.g_beta, bn.g_alpha, bn.coef)
 
-    def _bn_bwd(self, bn: _BN, dy, x_raw, dx, sums_rows: int = 0):
+    # decoder levels: the BatchNorm-backward apply of the up layer rides in the stride-2 convolution that
+    # consumes it (the transposed convolution's input gradient; csrc/conv_bnbwd_impl.h): du is written once
+    # for the weight gradient instead of written + read.  SEGMI_FUSE_APPLY_CONV=0: two launches (A/B).
+    fuse_apply_conv = os.environ.get("SEGMI_FUSE_APPLY_CONV", "1") != "0"
+
+    def _bn_bwd(self, bn: _BN, dy, x_raw, dx, sums_rows: int = 0, then_conv=None) -> bool:
         """``sums_rows`` > 0: the reduction's partial rows were written by the launch that produced dy
-        (``_dgrad(..., bsum=)``); only finalisation and apply remain"""
+        (``_dgrad(..., bsum=)``); only finalisation and apply remain.  ``then_conv`` = (conv, out): the
+        caller's next launch is ``out = dgrad(conv, dx)`` of a transposed convolution; returns True when
+        that convolution was done here, in the launch that computed dx."""
         count = x_raw.shape[0] * x_raw.shape[1] * x_raw.shape[2] * x_raw.shape[3]
         if (not sums_rows and self.fuse_bn_bwd_small and self.fuse_fin and self.dropout_p <= 0.0
                 and ops.bn_act_bwd_fused_ok(dy, x_raw, dx)):
@@ -726,7 +733,7 @@ class UNetEngine:
             rows = ops.bn_act_bwd_fused_rows(x_raw)
             ops.bn_act_bwd_fused(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
                                  self._fstat(rows, bn.c), self._bwd_fin(bn, x_raw))
-            return
+            return False
         if sums_rows:
             rows = sums_rows
             part = self._fstat(rows, bn.c)
@@ -738,8 +745,14 @@ class UNetEngine:
         if not self.fuse_fin:         # else: finalised by the launch that wrote the rows
             ops.bn_act_bwd_finalize(part, rows, bn.c, count, bn.gamma, bn.invstd, bn.g_gamma,
                                     bn.g_beta, bn.g_alpha, bn.coef)
+        if (then_conv is not None and self.fuse_apply_conv and self.dropout_p <= 0.0 and then_conv[0].transposed
+                and ops.bn_act_bwd_apply_conv_ok(dy, x_raw, dx, then_conv[1])):
+            ops.bn_act_bwd_apply_conv(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha, bn.coef,
+                                      then_conv[1], then_conv[0].dgrad_pack())
+            return True
         ops.bn_act_bwd_apply(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
                              bn.coef, dropout=bn.drop())
+        return False
 
     # ------------------------------------------------------------------ residual unit
     def _ru_fwd_train(self, ru, x, out, in_tf=None):
@@ -1014,12 +1027,13 @@ class UNetEngine:
         dau = self._buf(f"{p}dau", u.shape)
         rows = self._ru_bwd(lvl["upru"], dout, dx=dau, dx_bn=(lvl["upbn"], u))
         du = self._buf(f"{p}du", u.shape)
-        self._bn_bwd(lvl["upbn"], dau, u, du, sums_rows=rows)
         up = lvl["upconv"]
+        dcat = self._buf(f"{p}dcat", cat.shape)
+        conv_done = self._bn_bwd(lvl["upbn"], dau, u, du, sums_rows=rows, then_conv=(up, dcat))
         self._wgrad(up, cat, du, need_bias=False)
         self._grads_ready(self.param_offsets[f"model.{p}2.0.conv.weight"][0])
-        dcat = self._buf(f"{p}dcat", cat.shape)
-        self._dgrad(up, du, dcat)
+        if not conv_done:
+            self._dgrad(up, du, dcat)
         d_down, d_sub = dcat[..., :c], dcat[..., c:]
         dsum = self._buf(f"{p}ddown", (cat.shape[0], cat.shape[1], cat.shape[2], cat.shape[3], c))
         if lvl["sub"] is not None:

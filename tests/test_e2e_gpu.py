@@ -878,13 +878,14 @@ def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch)
     img, lab = synthetic_batch(batch, size, K, seed=5)
     batch_d = {"image": img.to(DEV), "label": lab.to(DEV)}
 
-    def run(defer, depth=None, carry=False, steps=3):
+    def run(defer, depth=None, carry=False, steps=3, apply_conv=True):
         _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
         net.mixed_precision = True
         net.train()
         eng = net._engine_for(batch_d["image"])
         eng.defer_top_wgrad = defer
         eng.carry_top_wgrad = carry
+        eng.fuse_apply_conv = apply_conv
         if depth is not None:
             eng._defer_depth_env = str(depth)
         for _ in range(steps):
@@ -906,6 +907,11 @@ def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch)
         assert torch.equal(w0, w), (defer, depth, carry)
         assert all(torch.equal(sd0[k], sd[k]) for k in sd0), (defer, depth, carry)
         assert torch.equal(y0, y), (defer, depth, carry)
+    # the up layers' BatchNorm-backward apply as its own launch instead of inside the stride-2 convolution
+    # that consumes it (segmi_bn_act_bwd_apply_conv): same bits
+    g, w, sd, y = run(True, None, True, apply_conv=False)
+    assert torch.equal(g0, g), ("apply_conv off", float((g0 - g).abs().max()))
+    assert torch.equal(w0, w) and torch.equal(y0, y)
 
 
 @pytest.mark.parametrize("vol,roi,overlap", [((96, 96, 96), 32, 0.5), ((72, 80, 88), 32, 0.25), ((64, 64, 70), 32, 0.5)])

@@ -1483,6 +1483,49 @@ def test_bn_backward_as_one_launch_matches_the_three_calls(c, sp, n, with_alpha,
     assert not ops.bn_act_bwd_fused_ok(big, big, big)
 
 
+@pytest.mark.parametrize("n,sp,cout,with_alpha,with_affine", [(2, (32, 32, 32), 32, True, True),
+                                                             (1, (18, 20, 34), 64, True, True),
+                                                             (1, (31, 33, 37), 16, False, True),
+                                                             (2, (16, 24, 40), 32, True, False)])
+def test_bn_backward_apply_inside_the_stride2_convolution_equals_the_two_calls(n, sp, cout, with_alpha, with_affine):
+    """segmi_bn_act_bwd_apply_conv: the BatchNorm / PReLU backward apply computed while the stride-2
+    convolution (a transposed convolution's input gradient) stages its halo tile.  dx and the convolution
+    result must equal segmi_bn_act_bwd_apply followed by segmi_conv3d_fwd bit for bit -- odd extents cover
+    partial tiles and the ownership rule (every dx voxel written exactly once)."""
+    c = 16
+    dtype = torch.bfloat16
+    x = rnd((n, c) + sp, 71, 2.0)
+    dy = rnd((n, c) + sp, 72)
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    mean = (rnd((c,), 73) * 0.5).to(DEV)
+    invstd = (rnd((c,), 74).abs() + 0.5).to(DEV)
+    gamma = (rnd((c,), 75) + 1.5).to(DEV) if with_affine else None
+    beta = (rnd((c,), 76) * 0.3).to(DEV) if with_affine else None
+    alpha = torch.full((1,), 0.25, device=DEV) if with_alpha else None
+    coef = (rnd((2, c), 77) * 0.1).to(DEV).contiguous()
+    w = (rnd((cout, c, 3, 3, 3), 78) * 0.1).to(DEV)
+    pack = ops.wpack(dtype, 0, w, c, cout, 3)
+    osp = tuple((v - 1) // 2 + 1 for v in sp)
+    out0 = torch.full((n,) + osp + (cout,), float("nan"), dtype=dtype, device=DEV)
+    out1 = torch.full_like(out0, float("nan"))
+    dx0 = torch.full_like(xd, float("nan"))
+    dx1 = torch.full_like(xd, float("nan"))
+    assert ops.bn_act_bwd_apply_conv_ok(dyd, xd, dx1, out1)
+    ops.bn_act_bwd_apply(dyd, xd, dx0, mean, invstd, gamma, beta, alpha, coef)
+    ops.conv3d_fwd(dx0, out0, pack, w, 0, None, 3, 2)
+    ops.bn_act_bwd_apply_conv(dyd, xd, dx1, mean, invstd, gamma, beta, alpha, coef, out1, pack)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx1.float()).all()) and bool(torch.isfinite(out1.float()).all())
+    bad = (dx0.view(torch.int16) != dx1.view(torch.int16))
+    assert not bool(bad.any()), (int(bad.sum()), bad.nonzero()[:4].tolist(),
+                                 float((dx0.float() - dx1.float()).abs().max()))
+    assert torch.equal(out0, out1), float((out0.float() - out1.float()).abs().max())
+    # not eligible: other channel counts, f32, aliased output
+    assert not ops.bn_act_bwd_apply_conv_ok(dyd.float(), xd.float(), dx1.float(), out1.float())
+    with pytest.raises(Exception):
+        ops.bn_act_bwd_apply_conv(dyd, xd, xd, mean, invstd, gamma, beta, alpha, coef, out1, pack)
+
+
 def test_cu_masked_stream_runs_kernels():
     """segmi_stream_create_cumask (hipExtStreamCreateWithCUMask): a stream restricted to 64 CUs computes the
     same bits as the default stream (measured as a scheduling tool in round 3 and not used: DESIGN section 6)."""
