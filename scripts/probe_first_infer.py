@@ -39,13 +39,18 @@ for name in ("segmi_conv3d_fwd", "segmi_convT3d_fwd", "segmi_dectop_fwd", "segmi
 torch.cuda.synchronize()
 rows = []
 t_all = time.perf_counter()
-for i in range(8):
+NV = 12
+for i in range(NV):
     acc.update(empty=0.0, launch=0.0, n_launch=0)
     st = {}
     t0 = time.perf_counter()
     with torch.no_grad():
         sliding_window_inference(vol, (128,) * 3, 4, net, overlap=0.5, return_labels=True, return_logits=False, stats=st)
-    rows.append((round((time.perf_counter() - t0) * 1e3, 1), round(acc["empty"] * 1e3, 1), round(acc["launch"] * 1e3, 1), acc["n_launch"]))
+    ms = torch.cuda.memory_stats()
+    rows.append((round((time.perf_counter() - t0) * 1e3, 1), round(acc["empty"] * 1e3, 1), round(acc["launch"] * 1e3, 1), acc["n_launch"],
+                 ms.get("num_device_alloc", -1), ms.get("num_device_free", -1), round(ms.get("reserved_bytes.all.current", 0) / 2**30, 1)))
 torch.cuda.synchronize()
-print("per volume (host ms total, in torch.empty, in C launches, launches):", rows)
-print("wall per volume", round((time.perf_counter() - t_all) / 8 * 1e3, 1), "ms")
+print("per volume (host ms total, in torch.empty, in C launches, launches, device allocs, device frees, reserved GiB):")
+for r_ in rows:
+    print("  ", r_)
+print("wall per volume", round((time.perf_counter() - t_all) / NV * 1e3, 1), "ms")

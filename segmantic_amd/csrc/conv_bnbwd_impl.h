@@ -108,10 +108,11 @@ __global__ __launch_bounds__(256, 3) void conv_s2_bnbwd_kernel(ConvBnBwdParams p
       const int v = vbase + 128 * (b * KB + k);
       const int hx = v % G::HW, hy = (v / G::HW) % G::HH, hz = v / (G::HW * G::HH);
       const int z = iz0 + hz, y = iy0 + hy, x = ix0 + hx;
-      const bool inside = v < NVX && (unsigned)z < (unsigned)p.Di && (unsigned)y < (unsigned)p.Hi &&
-                          (unsigned)x < (unsigned)p.Wi;
+      // (bitwise, not short-circuit: "&&" chains compile to exec-mask branches)
+      const bool inside = (v < NVX) & ((unsigned)z < (unsigned)p.Di) & ((unsigned)y < (unsigned)p.Hi) &
+                          ((unsigned)x < (unsigned)p.Wi);
       const int vox = (z * p.Hi + y) * p.Wi + x;
-      cd[k] = inside ? 2 * vox + ((hz >= 1 && hy >= 1 && hx >= 1) ? 1 : 0) : -1;
+      cd[k] = inside ? 2 * vox + (int)((hz >= 1) & (hy >= 1) & (hx >= 1)) : -1;
       dz[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, inside ? vox * p.ldy * 2 : kOob, 0, 0);
       xx[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, inside ? vox * p.ldx * 2 : kOob, 0, 0);
     }
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_bnbwd_kernel(ConvBnBwdParams p
         const f32x2 o2 = bn_bwd_apply_elem2g<HA>(a, d, m2[q], i2[q], g2[q], b2[q], c02[q], c12[q], gi2[q], alpha);
         val[q] = cd[k] >= 0 ? pack_bf16x2(o2[0], o2[1]) : 0u;      // zero padding stays zero
       }
-      __builtin_amdgcn_raw_buffer_store_b128(val, rs_dx, (cd[k] >= 0 && (cd[k] & 1)) ? (cd[k] >> 1) * p.lddx * 2 : kOob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(val, rs_dx, ((cd[k] >= 0) & ((cd[k] & 1) != 0)) ? (cd[k] >> 1) * p.lddx * 2 : kOob, 0, 0);
       *reinterpret_cast<frag_t*>(smem + v * G::ROWB + half * 16) = val;
     }
   };

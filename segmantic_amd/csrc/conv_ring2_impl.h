@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
+  constexpr int kDumpOff = G::LDS_BYTES + 6 * CK * 4;     // 256 x 16 bytes nobody reads (see the commit loop)
 
   // XCD-aware workgroup -> column map: XCD k (= blockIdx % 8) takes the k-th eighth of the columns
   // in raster order, so that x/y-neighbours share one L2 and their halos are fetched once.  L2 fetch
@@ -206,25 +207,39 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
   for (int ro = 0; ro < 2; ++ro) {
     const int oy = oy0 + 2 * wave + ro, ox = ox0 + r;
     row_ok[ro] = oy < p.Ho && ox < p.Wo;
-    o_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldo + co);
-    r_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldr + co);
+    o_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldo + co) * (unsigned)sizeof(T);     // bytes inside a plane
+    r_off[ro] = (unsigned)((oy * p.Wo + ox) * p.ldr + co) * (unsigned)sizeof(T);
   }
   const int64_t oplane = (int64_t)p.Ho * p.Wo * p.ldo, rplane = (int64_t)p.Ho * p.Wo * p.ldr;
   unsigned b_off[2];
 #pragma unroll
-  for (int ro = 0; ro < 2; ++ro) b_off[ro] = (unsigned)(((oy0 + 2 * wave + ro) * p.Wo + ox0 + r) * p.ldbx + co);
+  for (int ro = 0; ro < 2; ++ro)
+    b_off[ro] = (unsigned)(((oy0 + 2 * wave + ro) * p.Wo + ox0 + r) * p.ldbx + co) * (unsigned)sizeof(T);
   const int64_t bplane = (int64_t)p.Ho * p.Wo * p.ldbx;
 
   // Plane addresses are a per-workgroup 64-bit base (loop-invariant) + a 32-bit product (the launcher
   // checks that one sample's tensors stay below 2^31 elements): the 64-bit products
   // ((n * Do + oz) * plane) and the ring slot's "% R" were dependent scalar chains of 8-14
   // instructions per plane in front of every load / store group.
-  const char* const in_base = img + (int64_t)(z0 + 5) * plane_stride;         // plane z0 + 5
-  T* const out_base = outp + ((int64_t)n * p.Do + z0) * oplane;               // plane z0
-  const T* const res_base = resp ? resp + ((int64_t)n * p.Do + z0) * rplane : nullptr;
-  const T* const bx_base = BSUM ? bxp + ((int64_t)n * p.Do + z0) * bplane : nullptr;
-  const unsigned plane_b32 = (unsigned)plane_stride, oplane32 = (unsigned)oplane,
-                 rplane32 = (unsigned)rplane, bplane32 = (unsigned)bplane;
+  // Every global access of the step loop is a raw buffer operation over ONE SAMPLE of its tensor (the
+  // launcher checks that a sample stays below 2^32 bytes): wave-uniform descriptor, 32-bit per-lane byte
+  // offset = plane offset (scalar) + in-plane offset (per lane, computed once), and an out-of-range offset
+  // where the lane or the plane is outside the tensor -- the load then returns zeros (the zero padding), the
+  // store is dropped.  The first version guarded each access with an exec-mask branch: 79 s_and_saveexec /
+  // 56 s_cbranch_execz / 82 s_or_b64 per step, a third of the loop's 750 scalar instructions.
+  constexpr unsigned kOob = 0xFFFFFFFFu;
+  const unsigned plane_b32 = (unsigned)plane_stride, oplane_b = (unsigned)(oplane * (int64_t)sizeof(T)),
+                 rplane_b = (unsigned)(rplane * (int64_t)sizeof(T)), bplane_b = (unsigned)(bplane * (int64_t)sizeof(T));
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (int)((unsigned)p.Di * plane_b32), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(outp + (int64_t)n * p.Do * oplane), 0, (int)((unsigned)p.Do * oplane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(resp ? resp + (int64_t)n * p.Do * rplane : (const T*)p.out), 0, resp ? (int)((unsigned)p.Do * rplane_b) : 0,
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(BSUM ? bxp + (int64_t)n * p.Do * bplane : (const T*)p.out), 0, BSUM ? (int)((unsigned)p.Do * bplane_b) : 0,
+      0x00020000);
   int slot0 = 0;                                                               // zb % R
   auto ring_slot = [&](int c) { const int v = slot0 + c; return v >= G::R ? v - G::R : v; };
   // Staging loads: the 4 new planes step k + 1 computes from (z = z0 + 4k + 5 .. + 8) are committed to the
@@ -241,13 +256,12 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
     for (int pl = 0; pl < G::TD; ++pl) {
       const int z = z0 + zbk + 5 + pl;
-      const char* pp = in_base + (unsigned)(zbk + pl) * plane_b32;
+      const unsigned poff = (unsigned)z * plane_b32;
       const bool zok = morek && z < p.Di && !RING2_DBG(p, 1);
 #pragma unroll
-      for (int q = 0; q < NLP; ++q) {
-        dst[pl][q] = frag_t{0u, 0u, 0u, 0u};
-        if (zok && g_off[q] >= 0) dst[pl][q] = *reinterpret_cast<const frag_t*>(pp + (unsigned)g_off[q]);
-      }
+      for (int q = 0; q < NLP; ++q)
+        dst[pl][q] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs_in, (zok & (g_off[q] >= 0)) ? poff + (unsigned)g_off[q] : kOob, 0, 0);
     }
   };
   auto do_step = [&](const int step, frag_t (&stg)[G::TD][NLP], frag_t (&nxt)[G::TD][NLP]) {
@@ -264,13 +278,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
       for (int zi = 0; zi < 4; ++zi) {
         const int oz = z0 + zb + zi;
-        const T* rp = res_base + (unsigned)(zb + zi) * rplane32;
+        const unsigned poff = (unsigned)oz * rplane_b;
 #pragma unroll
         for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt)
-            resv[zi][ro][jt] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(rp + r_off[ro] + jt * 16)
-                                                         : typename Raw4<T>::type{};
+            resv[zi][ro][jt] = __builtin_amdgcn_raw_buffer_load_b64(
+                rs_res, ((oz < p.Do) & row_ok[ro]) ? poff + r_off[ro] + jt * 32 : kOob, 0, 0);
       }
     }
     // MODE 4: the BatchNorm's forward input at this step's output voxels.  Planes 0, 1 are fetched
@@ -279,13 +293,13 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
     typename Raw4<T>::type bxv[BSUM ? 4 : 1][2][NT];
     auto fetch_bx = [&](int zi) {
       const int oz = z0 + zb + zi;
-      const T* bp = bx_base + (unsigned)(zb + zi) * bplane32;
+      const unsigned poff = (unsigned)oz * bplane_b;
 #pragma unroll
       for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
-          bxv[BSUM ? zi : 0][ro][jt] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(bp + b_off[ro] + jt * 16)
-                                                                 : typename Raw4<T>::type{};
+          bxv[BSUM ? zi : 0][ro][jt] = __builtin_amdgcn_raw_buffer_load_b64(
+              rs_bx, ((oz < p.Do) & row_ok[ro]) ? poff + b_off[ro] + jt * 32 : kOob, 0, 0);
     };
     if constexpr (BSUM) { fetch_bx(0); fetch_bx(1); }
     // ---- compute: input plane c (z = zb - 1 + c) lives in ring slot (zb + c) % R
@@ -338,9 +352,17 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
           const bool zin = z0 + zb + 5 + pl < p.Di;
 #pragma unroll
           for (int q = 0; q < NLP; ++q) {
-            frag_t val = stg[pl][q];
-            if (zin && g_off[q] >= 0) val = tf(val);       // zero padding stays zero
-            if (l_off[q] >= 0) *reinterpret_cast<frag_t*>(smem + slot * G::PLANE_B + l_off[q]) = val;
+            // no exec-mask branches: the transform runs on every lane and is selected away where the lane is
+            // zero padding (the out-of-range load returned zeros); threads beyond the plane's chunks write a
+            // dump slot behind the ring
+            const frag_t raw = stg[pl][q];
+            const frag_t t4 = tf(raw);
+            const bool keep = zin & (g_off[q] >= 0);
+            frag_t val;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) val[c4] = keep ? t4[c4] : raw[c4];
+            const int la = l_off[q] >= 0 ? slot * G::PLANE_B + l_off[q] : kDumpOff + tid * 16;
+            *reinterpret_cast<frag_t*>(smem + la) = val;
           }
         }
       };
@@ -413,19 +435,20 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
     for (int zi = 0; zi < 4; ++zi) {
       const int oz = z0 + zb + zi;
-      T* op = out_base + (unsigned)(zb + zi) * oplane32;   // wave-uniform plane pointer
+      const unsigned opoff = (unsigned)oz * oplane_b;        // wave-uniform plane offset
+      const bool zin_out = oz < p.Do && !RING2_DBG(p, 2);
       const int rz = PRE_RES ? zi : 0;
       if constexpr (!PRE_RES) {
         if (res_in) {
           lds_res(zi, resv[0]);
         } else if (resp) {
-          const T* rp = res_base + (unsigned)(zb + zi) * rplane32;
+          const unsigned rpoff = (unsigned)oz * rplane_b;
 #pragma unroll
           for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
-              resv[0][ro][jt] = (oz < p.Do && row_ok[ro]) ? Raw4<T>::ld(rp + r_off[ro] + jt * 16)
-                                                          : typename Raw4<T>::type{};
+              resv[0][ro][jt] = __builtin_amdgcn_raw_buffer_load_b64(
+                  rs_res, ((oz < p.Do) & row_ok[ro]) ? rpoff + r_off[ro] + jt * 32 : kOob, 0, 0);
         }
         if (resp) {
 #pragma unroll
@@ -439,33 +462,37 @@ __global__ __launch_bounds__(256, CK == 16 ? 2 : 1) void conv_ring2_kernel(ConvP
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           f32x4 v = acc[zi][ro][jt] + bias4[jt];
-          if (oz < p.Do && row_ok[ro] && !RING2_DBG(p, 2)) {
-            if (want_stats) { ssum[jt] += v; ssq[jt] += v * v; }
-            if (has_alpha) {
+          const bool valid = zin_out & row_ok[ro];          // per lane; no branch: invalid lanes compute and drop
+          if (want_stats) {
+            const f32x4 vm = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            ssum[jt] += vm;
+            ssq[jt] += vm * vm;
+          }
+          if (has_alpha) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+          }
+          if (resp) v += Raw4<T>::cvt(resv[rz][ro][jt]);
+          u32x2 o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, valid ? opoff + o_off[ro] + jt * 32 : kOob, 0, 0);
+          if constexpr (BSUM) {
+            // the sums are taken of the STORED gradient (bf16-rounded), as the separate pass reads it; lanes
+            // outside the tensor contribute d = 0 to all three
+            f32x4 d = Raw4<T>::cvt(o);
+            if (!valid) d = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 xr = Raw4<T>::cvt(bxv[zi][ro][jt]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = fmaf(xr[e], bsc4[jt][e], bsh4[jt][e]);
+              float dz = d[e];
+              if (b_has_alpha && !(z > 0.f)) { bs2[jt][e] = fmaf(d[e], z, bs2[jt][e]); dz = balpha * d[e]; }
+              bs0[jt][e] += dz;
+              // sum dz * (x - mean), not sum dz * x corrected by mean * sum dz afterwards: the latter cancels
+              // badly when |mean| >> std; one subtraction per element
+              bs1[jt][e] = fmaf(dz, xr[e] - bmean4[jt][e], bs1[jt][e]);
             }
-            if (resp) v += Raw4<T>::cvt(resv[rz][ro][jt]);
-            if constexpr (BSUM) {
-              // the sums are taken of the STORED gradient (bf16-rounded), as the separate pass reads it
-              u32x2 o;
-              o[0] = pack_bf16x2(v[0], v[1]);
-              o[1] = pack_bf16x2(v[2], v[3]);
-              *reinterpret_cast<u32x2*>(op + o_off[ro] + jt * 16) = o;
-              const f32x4 d = Raw4<T>::cvt(o);
-              const f32x4 xr = Raw4<T>::cvt(bxv[zi][ro][jt]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float z = fmaf(xr[e], bsc4[jt][e], bsh4[jt][e]);
-                float dz = d[e];
-                if (b_has_alpha && !(z > 0.f)) { bs2[jt][e] = fmaf(d[e], z, bs2[jt][e]); dz = balpha * d[e]; }
-                bs0[jt][e] += dz;
-                // sum dz * (x - mean), not sum dz * x corrected by mean * sum dz afterwards: the latter cancels
-                // badly when |mean| >> std; one subtraction per element
-                bs1[jt][e] = fmaf(dz, xr[e] - bmean4[jt][e], bs1[jt][e]);
-              }
-            } else
-            store4<T>(op + o_off[ro] + jt * 16, v);
           }
         }
     }
@@ -563,15 +590,15 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
   p.xcd = xcd != 0 && grid.x % 8 == 0;
   constexpr bool kStats = (MODE & 2) != 0, kBsum = MODE == 4;
   p.fin_on = p.fin_on && (kStats || kBsum);
-  (void)fin_tail_arm(p, grid, 256, (kBsum ? 3 : 2) * p.Cout, G::LDS_BYTES + 6 * CK * 4);   // LDS: the ring is larger
+  (void)fin_tail_arm(p, grid, 256, (kBsum ? 3 : 2) * p.Cout, G::LDS_BYTES + 6 * CK * 4 + 4096);   // LDS: the ring is larger
   auto kern = conv_ring2_kernel<T, CK, NT, MODE>;
   static bool attr_done = false;
-  if (!attr_done && G::LDS_BYTES + 6 * CK * 4 > 64 * 1024) {
+  if (!attr_done && G::LDS_BYTES + 6 * CK * 4 + 4096 > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + 6 * CK * 4);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + 6 * CK * 4 + 4096);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES + 6 * CK * 4, st, p);
+  hipLaunchKernelGGL(kern, grid, 256, G::LDS_BYTES + 6 * CK * 4 + 4096, st, p);
   SEGMI_LAUNCH_CHECK("conv3d_fwd(ring2)");
   return SEGMI_OK;
 }

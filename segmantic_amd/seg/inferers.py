@@ -121,6 +121,45 @@ def group_factor() -> int:
     return max(1, int(os.environ.get("SEGMI_SW_GROUP", "4")))
 
 
+# The prediction cache of the deferred blend (every window's logits until they are blended: 23 GB for a 512^3
+# volume with 16 classes) is scratch of the driver, never handed to the caller.  It is kept across calls, one per
+# device: taken from torch's caching allocator per call, the freed block gets split by the smaller allocations in
+# between (count map, labels) and every few volumes a call pays a fresh 23 GB hipMalloc -- 0.5 s against 44 ms for
+# the whole volume (bench.py caught it as one timed volume in ten).  SEGMI_SW_KEEP_CACHE=0: allocate per call;
+# ``release_workspaces()`` returns the memory.
+_CACHE_WS: dict = {}
+
+
+def _cache_workspace(dev, shape, dtype):
+    """(buffer, event of the last call that used it or None)"""
+    dev = torch.device(dev)
+    if dev.type != "cuda" or os.environ.get("SEGMI_SW_KEEP_CACHE", "1") == "0":
+        return torch.empty(shape, dtype=dtype, device=dev), None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    hit = _CACHE_WS.get(key)
+    if hit is not None and tuple(hit[0].shape) == tuple(shape) and hit[0].dtype == dtype:
+        return hit[0], hit[1]
+    _CACHE_WS.pop(key, None)          # another shape: one live cache per device
+    buf = torch.empty(shape, dtype=dtype, device=dev)
+    _CACHE_WS[key] = [buf, None]
+    return buf, None
+
+
+def _cache_release_point(dev, stream):
+    """the call is done with the cache once `stream` gets here: the next call (possibly on another stream) waits"""
+    dev = torch.device(dev)
+    hit = _CACHE_WS.get(dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else None
+    if hit is not None:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        hit[1] = ev
+
+
+def release_workspaces() -> None:
+    """give the kept prediction cache(s) back to the allocator"""
+    _CACHE_WS.clear()
+
+
 def _cache_budget_bytes(device) -> int:
     free, _total = torch.cuda.mem_get_info(device)
     return int(free * 0.6)
@@ -346,11 +385,15 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
             if K is None:                                  # first group: pick the strategy
                 K = pn.shape[4]
                 need = (hi - lo) * nvox_roi * K * pn.element_size()
+                cshape = (hi - lo, roi[0], roi[1], roi[2], K)
+                kept = _CACHE_WS.get(dev.index) if dev.type == "cuda" else None
+                have = kept is not None and tuple(kept[0].shape) == cshape and kept[0].dtype == pn.dtype
                 deferred = blend != "stream" and max(len(v) for v in per_dim) <= 64 and (
-                    blend == "deferred" or need <= _cache_budget_bytes(dev))
+                    blend == "deferred" or have or need <= _cache_budget_bytes(dev))
                 if deferred:
-                    cache = torch.empty((hi - lo, roi[0], roi[1], roi[2], K), dtype=pn.dtype,
-                                        device=dev)
+                    cache, busy = _cache_workspace(dev, cshape, pn.dtype)
+                    if busy is not None:
+                        main.wait_event(busy)       # an earlier call's blend (any stream) still owns it
                 else:
                     acc = torch.zeros((1, orig[0], orig[1], orig[2], K), dtype=torch.float32,
                                       device=dev)
@@ -379,6 +422,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
             assert z_done == orig[0], (z_done, orig[0])
             main.wait_stream(_blend_stream(dev))
             acc, cnt, lab = acc_p, cnt_p, lab_p
+            _cache_release_point(dev, main)
             cache = None
             outs.append(acc); cnts.append(cnt); labs.append(lab if return_labels else None)
             continue
@@ -392,6 +436,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
             ops.sw_blend(cache, per_dim_b, lo, hi, roi, out_d, orig[1], orig[2], importance=imp,
                          out_logits=acc if want_logits else None, out_count=cnt, labels=lab,
                          normalize=not partial)
+            _cache_release_point(dev, main)
             cache = None
         elif not partial:
             if lab is None:

@@ -969,3 +969,45 @@ def test_pipelined_slab_blend_is_bit_identical(vol, roi, overlap, mode, monkeypa
     for a, b in zip(outs["0"], outs["1"]):
         assert torch.equal(a, b)
     assert torch.equal(outs["1"][1], outs["1"][3])
+
+
+def test_prediction_cache_is_kept_across_calls_and_changes_nothing(monkeypatch):
+    """The deferred blend's prediction cache is a workspace of the driver (kept per device, replaced when the
+    shape changes, SEGMI_SW_KEEP_CACHE=0: allocated per call): same labels and logits either way, for volumes
+    enqueued back to back without a device sync and on a caller-chosen stream, and `release_workspaces()`
+    gives the memory back."""
+    from segmantic_amd.seg import inferers
+    _, net = pair(16, (16, 32, 64), (2, 2))
+    net.eval()
+    net.mixed_precision = True
+    g = torch.Generator().manual_seed(44)
+    vols = [torch.randn((1, 1, 96, 96, 96), generator=g).to(DEV) for _ in range(3)]
+    small = torch.randn((1, 1, 64, 64, 64), generator=g).to(DEV)
+
+    def run(v, **kw):
+        with torch.no_grad():
+            return sliding_window_inference(v, (32,) * 3, 4, net, 0.5, return_labels=True, **kw)
+
+    monkeypatch.setenv("SEGMI_SW_KEEP_CACHE", "0")
+    inferers.release_workspaces()
+    ref = [run(v) for v in vols]
+    ref_small = run(small)
+    torch.cuda.synchronize()
+    assert not inferers._CACHE_WS
+    monkeypatch.setenv("SEGMI_SW_KEEP_CACHE", "1")
+    got = [run(v) for v in vols]                      # back to back, no sync in between
+    ptr = inferers._CACHE_WS[torch.device(DEV).index][0].data_ptr()
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                     # another stream: must wait for the last call's blend
+        got.append(run(vols[0]))
+    torch.cuda.current_stream().wait_stream(side)
+    assert inferers._CACHE_WS[torch.device(DEV).index][0].data_ptr() == ptr      # one buffer, reused
+    got_small = run(small)                            # another shape replaces it
+    assert inferers._CACHE_WS[torch.device(DEV).index][0].shape[0] != len(ref[0].labels) and len(inferers._CACHE_WS) == 1
+    torch.cuda.synchronize()
+    for a, b in zip(ref + [ref[0]], got):
+        assert torch.equal(a.labels, b.labels) and torch.equal(a.logits, b.logits)
+    assert torch.equal(ref_small.labels, got_small.labels) and torch.equal(ref_small.logits, got_small.logits)
+    inferers.release_workspaces()
+    assert not inferers._CACHE_WS
