@@ -4,7 +4,11 @@ import csv, sys
 from collections import defaultdict
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
-marks = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+# a step ends with the optimiser launch over the bulk of the arena; the carried suffix update (round 3: a
+# second, small launch of the same kernel early in the next step) is not a step boundary
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+big = max(int(rows[i]["Grid_Size_X"]) for i in adam)
+marks = [i for i in adam if int(rows[i]["Grid_Size_X"]) == big]
 seg = rows[marks[-2] + 1: marks[-1] + 1]
 agg = defaultdict(lambda: [0, 0])
 for r in seg:
