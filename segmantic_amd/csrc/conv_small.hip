@@ -198,32 +198,13 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   touch_s(alpha);
   __syncthreads();
 
-  // ---- wave w computes plane z = w of the tile; voxel tile i = row y = i (x = r)
-  f32x4 acc[8], acc2[PAIR ? 8 : 1];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (PAIR) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-      frag_t a;
-      if constexpr (ES == 2) {
-        unsigned short e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = xs[lk[s][j] + i * S * XW];
-        a = frag_t{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                   (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(xs[lk[s][j] + i * S * XW]);
-      }
-      acc[i] = mma16<T>(wf[s], a, acc[i]);
-      if constexpr (PAIR) acc2[i] = mma16<T>(wf2[s], a, acc2[i]);
-    }
-  }
-
-  // ---- epilogue: bias, BN statistics, PReLU, residual, 8/16-byte NDHWC stores; wave-uniform row
-  // pointers + one per-lane 32-bit offset
+  // ---- wave w computes plane z = w of the tile; voxel tile i = row y = i (x = r).  The 8 rows are done in
+  // two halves (MFMAs, then the epilogue of those 4 rows): with all 8 (x 2 convolutions) accumulated before
+  // the epilogue the kernel held 204 registers -- two workgroups per CU for a launch that is a chain of
+  // load -> barrier -> 16 MFMAs -> store latencies (95 us for the 224 MB of the training step's first layer).
+  constexpr int HB = 4;
+  // epilogue: bias, BN statistics, PReLU, residual, 8/16-byte NDHWC stores; wave-uniform row pointers + one
+  // per-lane 32-bit offset
   const int oz = oz0 + wave, ox = ox0 + r;
   const bool zx_ok = oz < p.Do && ox < p.Wo;
   T* orow = (T*)p.out + ((((int64_t)n * p.Do + oz) * p.Ho + oy0) * p.Wo) * p.ldo;
@@ -231,13 +212,13 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
                         : nullptr;
   const unsigned lo_out = (unsigned)(ox * p.ldo + co0 + 4 * g), lo_res = (unsigned)(ox * p.ldr + co0 + 4 * g);
   const int ostep = p.Wo * p.ldo, rstep = p.Wo * p.ldr;
-  f32x4 resv[8];
-  if (rrow) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      resv[i] = (zx_ok && oy0 + i < p.Ho) ? load4<T>(rrow + i * rstep + lo_res) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) touch_v(resv[i]);
+  T* orow2 = nullptr;
+  unsigned lo_out2 = 0u;
+  int ostep2 = 0;
+  if constexpr (PAIR) {
+    orow2 = (T*)p.out2 + ((((int64_t)n * p.Do + oz) * p.Ho + oy0) * p.Wo) * p.ldo2;
+    lo_out2 = (unsigned)(ox * p.ldo2 + co0 + 4 * g);
+    ostep2 = p.Wo * p.ldo2;
   }
 #pragma unroll
   for (int k = 0; k < NIT; ++k) touch_v(stg[k]);
@@ -247,25 +228,58 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   }
   f32x4 ssum = f32x4{0.f, 0.f, 0.f, 0.f}, ssq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    f32x4 v = acc[i] + bias4;
-    if (zx_ok && oy0 + i < p.Ho) {
-      if (p.stats) { ssum += v; ssq += v * v; }
-      if (has_alpha) {
+  for (int hb = 0; hb < 8; hb += HB) {
+    f32x4 resv[HB];
+    if (rrow) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
-      }
-      if (rrow) v += resv[i];
-      store4<T>(orow + i * ostep + lo_out, v);
+      for (int i = 0; i < HB; ++i)
+        resv[i] = (zx_ok && oy0 + hb + i < p.Ho) ? load4<T>(rrow + (hb + i) * rstep + lo_res)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  if constexpr (PAIR) {
-    T* orow2 = (T*)p.out2 + ((((int64_t)n * p.Do + oz) * p.Ho + oy0) * p.Wo) * p.ldo2;
-    const unsigned lo_out2 = (unsigned)(ox * p.ldo2 + co0 + 4 * g);
-    const int ostep2 = p.Wo * p.ldo2;
+    f32x4 acc[HB], acc2[PAIR ? HB : 1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (zx_ok && oy0 + i < p.Ho) store4<T>(orow2 + i * ostep2 + lo_out2, acc2[i] + bias4b);
+    for (int i = 0; i < HB; ++i) {
+      acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PAIR) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NK; ++s) {
+        frag_t a;
+        if constexpr (ES == 2) {
+          unsigned short e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = xs[lk[s][j] + (hb + i) * S * XW];
+          a = frag_t{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                     (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(xs[lk[s][j] + (hb + i) * S * XW]);
+        }
+        acc[i] = mma16<T>(wf[s], a, acc[i]);
+        if constexpr (PAIR) acc2[i] = mma16<T>(wf2[s], a, acc2[i]);
+      }
+    }
+    if (rrow) {
+#pragma unroll
+      for (int i = 0; i < HB; ++i) touch_v(resv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      f32x4 v = acc[i] + bias4;
+      if (zx_ok && oy0 + hb + i < p.Ho) {
+        if (p.stats) { ssum += v; ssq += v * v; }
+        if (has_alpha) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
+        }
+        if (rrow) v += resv[i];
+        store4<T>(orow + (hb + i) * ostep + lo_out, v);
+      }
+    }
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int i = 0; i < HB; ++i)
+        if (zx_ok && oy0 + hb + i < p.Ho) store4<T>(orow2 + (hb + i) * ostep2 + lo_out2, acc2[i] + bias4b);
+    }
   }
   if (p.stats) {
     __syncthreads();
