@@ -235,24 +235,37 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(EwParams p) {
     bet[k] = ok ? (p.p3 ? p.p3[ch] : 0.f) : 0.f;
   }
   if (my_v < vpp) {
-    for (int64_t v = v0 + my_v; v < v1; v += vpp) {
-      float a[VEC], d[VEC];
-      loadv<T, VEC>(x + v * p.ldx + my_cg * VEC, a);
-      loadv<T, VEC>(dy + v * p.ldy + my_cg * VEC, d);
+    // four voxels per trip, loads first (same per-thread summation order: same bits); one voxel per trip
+    // kept one 8-byte load per tensor in flight per thread: 3.3 TB/s
+    constexpr int U = 4;
+    for (int64_t vb = v0 + my_v; vb < v1; vb += (int64_t)U * vpp) {
+      float a[U][VEC], d[U][VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const float xh = (a[k] - mean[k]) * istd[k];
-        float z = fmaf(xh, gam[k], bet[k]);
-        float m = 1.f;
-        if (p.drop_thresh) {
-          m = drop_mult(p.drop_seed, v * p.c + my_cg * VEC + k, p.drop_thresh, p.drop_scale);
-          z *= m;
+      for (int u = 0; u < U; ++u) {
+        const int64_t vu = vb + (int64_t)u * vpp < v1 ? vb + (int64_t)u * vpp : vb;
+        loadv<T, VEC>(x + vu * p.ldx + my_cg * VEC, a[u]);
+        loadv<T, VEC>(dy + vu * p.ldy + my_cg * VEC, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = vb + (int64_t)u * vpp;
+        if (v < v1) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const float xh = (a[u][k] - mean[k]) * istd[k];
+            float z = fmaf(xh, gam[k], bet[k]);
+            float m = 1.f;
+            if (p.drop_thresh) {
+              m = drop_mult(p.drop_seed, v * p.c + my_cg * VEC + k, p.drop_thresh, p.drop_scale);
+              z *= m;
+            }
+            float dz = d[u][k];
+            if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[u][k], z, s2[k]); dz = alpha * d[u][k]; }
+            dz *= m;
+            s0[k] += dz;
+            s1[k] = fmaf(dz, xh, s1[k]);
+          }
         }
-        float dz = d[k];
-        if (has_alpha && !(z > 0.f)) { s2[k] = fmaf(d[k], z, s2[k]); dz = alpha * d[k]; }
-        dz *= m;
-        s0[k] += dz;
-        s1[k] = fmaf(dz, xh, s1[k]);
       }
     }
   }
