@@ -231,6 +231,12 @@ int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
                        float* db, int ksize, int stride, void* workspace,
                        const segmi_in_affine* in_tf /* transform of x, nullable */, void* stream);
+/* How many compute units the weight-gradient kernels size their grids for (a multiple of 8 in [8, 256]; 0 =
+ * back to the default, the whole chip; the environment variable SEGMI_WGRAD_CUS overrides any call).  Their
+ * workgroups hold a CU exclusively, so a caller that runs them on a side stream beside its dependent chain --
+ * what autograd's single stream cannot do, monai_unet.py:345 -- sizes them for part of the chip.  Process-wide;
+ * it changes segmi_conv3d_wgrad_workspace(): set it before querying.  Returns the value in effect before. */
+int segmi_wgrad_set_cus(int cus);
 /* bias gradient only: db[c] = sum over voxels of dy */
 int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream);
 

@@ -123,6 +123,7 @@ SIGNATURES = {
     "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
     "segmi_bn_act_bwd_apply_conv_ok": (_i, [_i, _AP, _AP, _AP, _AP]),
     "segmi_bn_act_bwd_apply_conv": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _AP, _P, _P]),
+    "segmi_wgrad_set_cus": (_i, [_i]),
     "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),
     "segmi_cast_copy": (_i, [_i, _AP, _i, _AP, _P]),
     "segmi_nchw_to_ndhwc": (_i, [_P, _i, _AP, _P]),

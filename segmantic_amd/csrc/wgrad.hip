@@ -2,6 +2,23 @@
 #include "wgrad_impl.h"
 #include "reduce_fin.h"
 
+#include <atomic>
+namespace segmi {
+static std::atomic<int> g_wgrad_cus{0};        // 0 = not set: SEGMI_WGRAD_CUS or the whole chip
+static inline int clamp_cus(int n) {
+  n = n / 8 * 8;
+  return n < 8 ? 8 : (n > 256 ? 256 : n);
+}
+int wgrad_cus() {
+  static const int env = [] {
+    const char* e = getenv("SEGMI_WGRAD_CUS");
+    return e ? clamp_cus(atoi(e)) : 0;
+  }();
+  if (env) return env;                          // an exported value wins (A/B runs)
+  const int v = g_wgrad_cus.load(std::memory_order_relaxed);
+  return v ? v : 256;
+}
+}  // namespace segmi
 namespace segmi {
 
 int wgrad_mfma_f32(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
@@ -118,6 +135,13 @@ static inline int wg_slabs(int dtype, const segmi_act* x, const segmi_act* dy, i
 using namespace segmi;
 
 extern "C" {
+
+int segmi_wgrad_set_cus(int cus) {
+  const int prev = segmi::wgrad_cus();
+  segmi::g_wgrad_cus.store(cus > 0 ? segmi::clamp_cus(cus) : 0, std::memory_order_relaxed);
+  return prev;
+}
+
 
 int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_act* dy,
                                      int ksize, int stride) {

@@ -366,18 +366,11 @@ static inline bool wgrad_ws_cfg_ok(int stride, int ct) {
   (void)stride;
   return ct == 11 || ct == 21;
 }
-// CUs the persistent weight-gradient kernels size their grids for (default: the whole chip).  With the
-// weight-gradient stream restricted to a CU mask (segmi_stream_create_cumask, SEGMI_SIDE_CUS) the grid
-// must match the mask or a second, ragged round of workgroups appears.
-static inline int wgrad_cus() {
-  static const int v = [] {
-    const char* e = getenv("SEGMI_WGRAD_CUS");
-    int n = e ? atoi(e) : 256;
-    n = n / 8 * 8;
-    return n < 8 ? 8 : (n > 256 ? 256 : n);
-  }();
-  return v;
-}
+// CUs the weight-gradient kernels size their grids for (segmi_wgrad_set_cus; SEGMI_WGRAD_CUS overrides).  These
+// kernels hold a CU exclusively (one 768-thread or 400-register workgroup per CU), so with one workgroup on
+// EVERY CU the dependent chain of the main stream gets no CU until they retire; sized for half the chip the two
+// streams really run side by side (5.55 -> 5.28 ms per training step, round 3).
+int wgrad_cus();
 static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride) {
   static const bool enabled = !(getenv("SEGMI_WGRAD_WS") && atoi(getenv("SEGMI_WGRAD_WS")) == 0);
   if (!enabled || dtype != SEGMI_BF16 || ksize != 3) return 0;

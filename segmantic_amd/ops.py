@@ -194,6 +194,12 @@ def conv3d_bn_bwd_sums_ok(x, y, ksize, stride) -> bool:
     return bool(lib.segmi_conv3d_bn_bwd_sums_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
 
 
+def wgrad_set_cus(cus: int) -> int:
+    """compute units the weight-gradient kernels size their grids for (segmi_wgrad_set_cus); returns the
+    previous value"""
+    return int(lib.segmi_wgrad_set_cus(int(cus)))
+
+
 def cu_masked_stream(cus_enabled: int, device=None) -> "torch.cuda.Stream":
     """A torch stream over a HIP stream restricted to the first ``cus_enabled / 8`` CUs of every XCD
     (segmi_stream_create_cumask).  The HIP stream lives as long as the process."""

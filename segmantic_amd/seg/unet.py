@@ -306,6 +306,8 @@ class UNetEngine:
         self._saved: Dict[str, torch.Tensor] = {}
         self.timings: Dict[str, list] = {}
         self._carry_convs: set = set()
+        # weight-gradient kernels beside the main chain: grids sized for half the chip (see wgrad_cus_overlap)
+        ops.wgrad_set_cus(self.wgrad_cus_overlap if self.overlap_wgrad else 0)
         self.fixed_slope = torch.full((1,), FIXED_SLOPE.get(params.act, 0.0), dtype=torch.float32,
                                       device=self.device)
         self._build_arena()
@@ -1264,6 +1266,14 @@ class UNetEngine:
     # SEGMI_SERIAL=1 keeps every kernel on one stream (per-kernel profiling without co-running work)
     overlap_wgrad = os.environ.get("SEGMI_SERIAL", "0") != "1"
     _side = None
+    # CUs the weight-gradient kernels size their grids for while they run on the side stream
+    # (segmi_wgrad_set_cus; SEGMI_WGRAD_CUS overrides).  Their workgroups hold a CU exclusively (768 threads
+    # or ~400 registers each): one per CU on all 256 and the main chain's kernels wait for a CU to retire --
+    # "overlap" was then mostly alternation.  Sized for half the chip both streams run: 5.55 -> 5.28 ms per
+    # step (160: 5.40, 96: 5.53, 64: 5.93; `gpurun_out/r3/wcus_ab2.txt`).  Round 2 measured the same knob
+    # neutral; what changed is that the deferred / carried schedule now puts these kernels beside the
+    # latency-bound levels of the main chain, which need CUs, not bandwidth.
+    wgrad_cus_overlap = 128
 
     # SEGMI_SIDE_CUS=k: the weight-gradient stream may use only k CUs (k / 8 per XCD; a CU-masked HIP
     # stream) -- set SEGMI_WGRAD_CUS to the same value so the persistent kernels size their grids for it
