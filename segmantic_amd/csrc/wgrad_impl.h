@@ -399,7 +399,9 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
   // workgroups wanted = a multiple of the 256 CUs; one per CU once the kernel holds > 1 channel
   // tile (200-400 VGPRs, 55-110 KB slabs).  Measured on MI355X: 1x1 blocks
   // 704/508/540/608 us at 256/512/1024/2048 workgroups, 2x2 blocks 125/198/348 us at 256/512/1024.
-  const int target = cto * cti == 1 ? 2 * wgrad_cus() : wgrad_cus();
+  static const int mfma_env = getenv("SEGMI_WGRAD_CUS_MFMA") ? atoi(getenv("SEGMI_WGRAD_CUS_MFMA")) / 8 * 8 : 0;   // experiments
+  const int cus = mfma_env >= 8 ? mfma_env : wgrad_cus();
+  const int target = cto * cti == 1 ? 2 * cus : cus;
   int gx = target / chunks;
   if (gx < 1) gx = 1;
   const int nt = wgrad_tiles(dy, stride, cto * cti == 1);

@@ -1310,9 +1310,13 @@ class UNetEngine:
     # (alternating runs, one box; flushing one level earlier: no gain, at the very end: 6.2 ms).
     # Not with a grad_hook (data parallel): the arena suffix would become final later and every gradient
     # bucket with it (tried with the notifications held back until the flush: 5.89-5.94 vs 5.86-5.87 ms
-    # per step with the buckets going through RCCL on one rank).  SEGMI_DEFER_TOP_WGRAD=0 issues every weight gradient as soon as its operands exist;
-    # SEGMI_DEFER_DEPTH overrides the level at which the queue is flushed.
-    defer_top_wgrad = os.environ.get("SEGMI_DEFER_TOP_WGRAD", "1") != "0"
+    # per step with the buckets going through RCCL on one rank).  SEGMI_DEFER_DEPTH overrides the level at which
+    # the queue is flushed.
+    # OFF by default since the weight-gradient kernels are sized for half the chip (wgrad_cus_overlap): they no
+    # longer take every CU away from the main chain, and the earlier they start the more of them hides --
+    # 5.20-5.29 without against 5.32-5.40 ms with the deferral, three alternating runs on one box, 5.17-5.23
+    # against 5.23-5.30 on another (`gpurun_out/r3/sched_ab.txt`, `sched2_ab.txt`).  SEGMI_DEFER_TOP_WGRAD=1: on.
+    defer_top_wgrad = os.environ.get("SEGMI_DEFER_TOP_WGRAD", "0") != "0"
     _diag_skip_wgrad = os.environ.get("SEGMI_DIAG_SKIP_WGRAD") == "1"      # WRONG gradients: timing probes only
     _defer_depth_env = os.environ.get("SEGMI_DEFER_DEPTH")
 
