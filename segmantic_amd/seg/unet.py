@@ -489,13 +489,21 @@ class UNetEngine:
     def _build_plan(self):
         chs, sts = list(self.net.channels), list(self.net.strides)
         self.levels = self._make_level("", self.net.in_channels, self.kpad, chs, sts, True)
-        # carried weight gradients (see carry_top_wgrad): the two full-resolution decoder convolutions;
-        # their parameters (with the BatchNorm between them) are the contiguous END of the arena
-        top = self.levels
-        self._carry_convs = {top["upconv"]} | {c for c, _ in top["upru"]["units"]}
-        self.carry_lo = self.param_offsets["model.2.0.conv.weight"][0]
-        assert all(off >= self.carry_lo for name, (off, _n) in self.param_offsets.items() if name.startswith("model.2.")) \
-            and all(off < self.carry_lo for name, (off, _n) in self.param_offsets.items() if not name.startswith("model.2."))
+        # carried weight gradients (see carry_top_wgrad): the up path (transposed conv + unit) of the upper
+        # `carry_levels` levels; their parameters (with the BatchNorms between them) are the contiguous END of
+        # the arena, in the order a forward reaches them (MONAI's nesting = depth-first order)
+        lv, carried = self.levels, []
+        while lv is not None and len(carried) < max(1, self.carry_levels):
+            carried.append(lv)
+            lv = lv.get("sub")
+        self._carry_lvls = [id(l) for l in carried]
+        self._carry_convs = set()
+        for l in carried:
+            self._carry_convs |= {l["upconv"]} | {c for c, _ in l["upru"]["units"]}
+        pre = tuple(f"model.{l['prefix']}2." for l in carried)
+        self.carry_lo = self.param_offsets[f"model.{carried[-1]['prefix']}2.0.conv.weight"][0]
+        assert all(off >= self.carry_lo for name, (off, _n) in self.param_offsets.items() if name.startswith(pre)) \
+            and all(off < self.carry_lo for name, (off, _n) in self.param_offsets.items() if not name.startswith(pre))
 
     def _make_ru(self, prefix, cin, cout, stride, subunits, last_conv_only=False):
         units = []
@@ -953,7 +961,8 @@ class UNetEngine:
         n, d, h, w = self._down_shape(x.shape, lvl["stride"])
         c, upc, subc = lvl["c"], lvl["upc"], lvl["subc"]
         tag = "t" if train else "e"
-        if train and lvl["is_top"] and self.carry_top_wgrad and self.grad_hook is None and self.overlap_wgrad:
+        if (train and id(lvl) in self._carry_lvls and self.carry_top_wgrad and self.grad_hook is None
+                and self.overlap_wgrad):
             # the carried transposed-conv weight gradient of the LAST step may still be reading the last
             # step's skip buffer: alternate between two
             tag = "t" + str(self._fwd_parity)
@@ -969,7 +978,7 @@ class UNetEngine:
         up, ubn = lvl["upconv"], lvl["upbn"]
         oshape = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], lvl["outc"])
         if train:
-            if lvl["is_top"]:
+            if id(lvl) in self._carry_lvls:
                 self.sync_weights()        # parameters of the carried layers, and their readers of u / scale / shift
             u = self._buf(f"{p}u", oshape)
             self._conv_train(up, cat, u, ubn)
@@ -1212,6 +1221,8 @@ class UNetEngine:
     # top transposed convolution.  Same arithmetic in the same order per parameter: bit-identical weights
     # (tests/test_e2e_gpu.py).  SEGMI_CARRY_TOP_WGRAD=0: everything inside the step, as before.
     carry_top_wgrad = os.environ.get("SEGMI_CARRY_TOP_WGRAD", "1") != "0"
+    # how many of the upper levels' up paths are carried (1 = the full-resolution decoder only)
+    carry_levels = int(os.environ.get("SEGMI_CARRY_LEVELS", "1"))
     _carry_open = False
     _carried: list = []
     _tail_ev = None

@@ -878,11 +878,18 @@ def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch)
     img, lab = synthetic_batch(batch, size, K, seed=5)
     batch_d = {"image": img.to(DEV), "label": lab.to(DEV)}
 
-    def run(defer, depth=None, carry=False, steps=3, apply_conv=True):
+    def run(defer, depth=None, carry=False, steps=3, apply_conv=True, carry_levels=1):
+        from segmantic_amd.seg.unet import UNetEngine
         _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
         net.mixed_precision = True
         net.train()
-        eng = net._engine_for(batch_d["image"])
+        keep = UNetEngine.carry_levels
+        UNetEngine.carry_levels = carry_levels          # read when the engine lays out its plan
+        try:
+            eng = net._engine_for(batch_d["image"])
+        finally:
+            UNetEngine.carry_levels = keep
+        assert len(eng._carry_lvls) == carry_levels
         eng.defer_top_wgrad = defer
         eng.carry_top_wgrad = carry
         eng.fuse_apply_conv = apply_conv
@@ -907,6 +914,12 @@ def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch)
         assert torch.equal(w0, w), (defer, depth, carry)
         assert all(torch.equal(sd0[k], sd[k]) for k in sd0), (defer, depth, carry)
         assert torch.equal(y0, y), (defer, depth, carry)
+    # the up paths of the two / three upper levels carried over the step boundary
+    for lv in (2, 3):
+        g, w, sd, y = run(False, None, True, carry_levels=lv)
+        assert torch.equal(g0, g), ("carry levels", lv, float((g0 - g).abs().max()))
+        assert torch.equal(w0, w) and torch.equal(y0, y), ("carry levels", lv)
+        assert all(torch.equal(sd0[k], sd[k]) for k in sd0), ("carry levels", lv)
     # the up layers' BatchNorm-backward apply as its own launch instead of inside the stride-2 convolution
     # that consumes it (segmi_bn_act_bwd_apply_conv): same bits
     g, w, sd, y = run(True, None, True, apply_conv=False)
