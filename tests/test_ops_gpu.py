@@ -422,6 +422,38 @@ def test_conv3d_wgrad(case, dtype):
     assert relerr(db.cpu(), b0.grad) < 5e-5
 
 
+@pytest.mark.parametrize("case", [(16, 16, 3, 1, (32, 32, 32), 2), (32, 64, 3, 2, (16, 16, 16), 2)])
+def test_wgrad_grid_budget_changes_the_partition_not_the_gradient(case):
+    """segmi_wgrad_set_cus: the weight-gradient kernels size their grids (and their partial slabs) for that many
+    compute units -- the engine gives them half the chip beside the main chain.  Any budget yields the gradient
+    of the torch reference (another partition of the same f32 sums); the call returns the previous value, 0
+    restores the default, values are clamped to multiples of 8 in [8, 256]."""
+    cin, cout, k, s, sp, n = case
+    dtype = torch.bfloat16
+    x = rnd((n, cin) + sp, 131)
+    osp = tuple((d + 2 * ((k - 1) // 2) - k) // s + 1 for d in sp)
+    dy = rnd((n, cout) + osp, 132)
+    w0 = torch.zeros((cout, cin, k, k, k), requires_grad=True)
+    F.conv3d(q(x, dtype), w0, None, stride=s, padding=(k - 1) // 2).backward(q(dy, dtype))
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    first = ops.wgrad_set_cus(0)
+    try:
+        assert ops.wgrad_set_cus(64) in (256, first) and ops.wgrad_set_cus(1000) == 64 and ops.wgrad_set_cus(3) == 256
+        assert ops.wgrad_set_cus(0) == 8
+        got = {}
+        for cus in (256, 128, 64, 8):
+            ops.wgrad_set_cus(cus)
+            dw = torch.full_like(w0, float("nan"), device=DEV)
+            ws = torch.empty(ops.conv3d_wgrad_workspace(xd, dyd, k, s), dtype=torch.uint8, device=DEV)
+            ops.conv3d_wgrad(xd, dyd, dw, None, k, s, ws)
+            torch.cuda.synchronize()
+            assert relerr(dw.cpu(), w0.grad) < 5e-5, cus
+            got[cus] = dw.cpu()
+        assert float((got[256] - got[64]).abs().max()) <= 1e-4 * float(got[256].abs().max())
+    finally:
+        ops.wgrad_set_cus(first if first != 256 else 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_convT3d_wgrad_via_conv_wgrad(dtype):
     """ConvTranspose3d weight grad == stride-2 conv wgrad with x := dy_T, dy := x_T."""
