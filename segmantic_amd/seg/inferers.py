@@ -87,7 +87,11 @@ def default_lanes() -> int:
     schedule repeatedly ran host-bound at 5 volumes/s (168 ms instead of 8 ms to enqueue a volume's window
     groups, lane busy times unchanged, the one-lane run seconds later in the same process at 20+) -- the
     round-2 driver figure of 17.5 against the builder's 21.3.  One lane does not have that failure mode;
-    bench.py reports both."""
+    bench.py reports both.  (Later in round 3 the slow first volumes were traced to allocations of the prediction
+    cache, not to the lane count, and removed: `_cache_workspace`.  Two lanes now measure +1.5 .. +3 % whichever
+    count is timed first, three lanes +5 % (`gpurun_out/r3/lanes_order.txt`, `lanes_n.txt`).  The default stays 1:
+    with several lanes a launch's duration is that of two co-running launches, which makes per-kernel rooflines
+    of the line unreadable; `lanes=` / SEGMI_SW_LANES for throughput.)"""
     if os.environ.get("SEGMI_SERIAL"):
         return 1
     return max(1, int(os.environ.get("SEGMI_SW_LANES", "1")))
