@@ -227,16 +227,17 @@ int segmi_convT3d_fwd(int dtype, const segmi_act* in, const segmi_act* out, cons
  * Replaces autograd's conv backward reached from manual_backward,
  * src/segmantic/seg/monai_unet.py:345. */
 int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_act* dy,
-                                     int ksize, int stride);
+                                     int ksize, int stride, int cus);
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
                        float* db, int ksize, int stride, void* workspace,
-                       const segmi_in_affine* in_tf /* transform of x, nullable */, void* stream);
-/* How many compute units the weight-gradient kernels size their grids for (a multiple of 8 in [8, 256]; 0 =
- * back to the default, the whole chip; the environment variable SEGMI_WGRAD_CUS overrides any call).  Their
- * workgroups hold a CU exclusively, so a caller that runs them on a side stream beside its dependent chain --
- * what autograd's single stream cannot do, monai_unet.py:345 -- sizes them for part of the chip.  Process-wide;
- * it changes segmi_conv3d_wgrad_workspace(): set it before querying.  Returns the value in effect before. */
-int segmi_wgrad_set_cus(int cus);
+                       const segmi_in_affine* in_tf /* transform of x, nullable */, int cus, void* stream);
+/* `cus`: how many compute units the weight-gradient kernels size their grid (and their partial slabs: pass the same
+ * value to the workspace query) for -- a multiple of 8 in [8, 256]; <= 0 = the whole chip.  Their workgroups hold a
+ * CU exclusively, so a caller that runs them on a side stream beside its dependent chain -- what autograd's single
+ * stream cannot do, monai_unet.py:345 -- sizes them for part of the chip.  A per-call argument since round 4 (no
+ * process-wide state); the environment variable SEGMI_WGRAD_CUS overrides it for A/B runs.  segmi_wgrad_cus(cus)
+ * returns the count a call with that argument would use. */
+int segmi_wgrad_cus(int cus);
 /* bias gradient only: db[c] = sum over voxels of dy */
 int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream);
 
@@ -275,16 +276,29 @@ int segmi_bn_act_bwd_finalize(const float* red_partials, int rows, int c, double
                               const float* gamma, const float* invstd, float* dgamma,
                               float* dbeta, float* dalpha, float* coef, void* stream);
 /* The three calls above as ONE launch for small tensors (<= 32 MB, <= 256 channels in multiples of 4, no
- * dropout): <= 256 workgroups reduce, the last one finalises and publishes the coefficients, all apply
+ * dropout): the workgroups reduce, the last one finalises and publishes the coefficients, all apply
  * (a grid-wide hand-off through device-scope atomics; csrc/norm_act.hip).  red_partials: f32
  * [segmi_bn_act_bwd_fused_rows(x)][3][c].  Same results as the three calls up to the f32 summation order of the
- * partial rows.  Replaces autograd's BatchNorm / PReLU backward under monai ADN, monai_unet.py:114-124, 345. */
+ * partial rows.  Replaces autograd's BatchNorm / PReLU backward under monai ADN, monai_unet.py:114-124, 345.
+ * Residency: a workgroup of this launch holds a whole CU and waits on it for the last one, so the launch uses at
+ * most as many workgroups as the device holds at once (occupancy query x compute units; _ok returns 0 on a device
+ * that cannot hold one) and at most `max_wgs` (> 0): a caller that runs CU-exclusive kernels on another stream
+ * (segmi_conv3d_wgrad with `cus`) passes the CUs they leave free; <= 0 = the device's capacity.
+ * segmi_bn_act_bwd_fused_wgs: the workgroup count a call would launch.  A waiting workgroup gives up after a
+ * bounded number of polls (about a second), writes NaN gradients and counts the expiry; segmi_fused_timeouts(reset)
+ * returns the count from host-visible memory WITHOUT a device sync (expiries of launches that have executed so far)
+ * -- a non-zero value means gradients of this process are poisoned (the reference stops on a non-finite
+ * loss, monai_unet.py:512-518 `check_finite`); the Python engine raises.  segmi_fused_test_hook: tests only --
+ * a poll bound (0 = default) and `no_publish` (the finalising workgroup withholds the flag: every waiter expires). */
 int segmi_bn_act_bwd_fused_ok(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx);
 int segmi_bn_act_bwd_fused_rows(const segmi_act* x);
+int segmi_bn_act_bwd_fused_wgs(int dtype, const segmi_act* x, int max_wgs);
 int segmi_bn_act_bwd_fused(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* prelu_alpha, float* red_partials, const segmi_bn_bwd_fin* fin,
-                           void* stream);
+                           int max_wgs, void* stream);
+unsigned segmi_fused_timeouts(int reset);
+int segmi_fused_test_hook(unsigned poll_limit, int no_publish);
 int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
                            const segmi_act* dx, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const float* prelu_alpha,

@@ -105,8 +105,8 @@ SIGNATURES = {
                                    C.POINTER(Windows), _P]),
     "segmi_convT3d_stats_rows": (_i, [_i, _AP, _AP]),
     "segmi_convT3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _P, _P, _AP, _P, C.POINTER(BnFin), _P]),
-    "segmi_conv3d_wgrad_workspace": (_i64, [_i, _AP, _AP, _i, _i]),
-    "segmi_conv3d_wgrad": (_i, [_i, _AP, _AP, _P, _P, _i, _i, _P, C.POINTER(InAffine), _P]),
+    "segmi_conv3d_wgrad_workspace": (_i64, [_i, _AP, _AP, _i, _i, _i]),
+    "segmi_conv3d_wgrad": (_i, [_i, _AP, _AP, _P, _P, _i, _i, _P, C.POINTER(InAffine), _i, _P]),
     "segmi_bias_grad": (_i, [_i, _AP, _P, _P, _P]),
     "segmi_bn_stats_rows": (_i, [_AP]),
     "segmi_bn_stats": (_i, [_i, _AP, _P, _P]),
@@ -119,11 +119,14 @@ SIGNATURES = {
     "segmi_bn_act_bwd_finalize": (_i, [_P, _i, _i, _d, _P, _P, _P, _P, _P, _P, _P]),
     "segmi_bn_act_bwd_fused_ok": (_i, [_i, _AP, _AP, _AP]),
     "segmi_bn_act_bwd_fused_rows": (_i, [_AP]),
-    "segmi_bn_act_bwd_fused": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwdFin), _P]),
+    "segmi_bn_act_bwd_fused": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwdFin), _i, _P]),
+    "segmi_bn_act_bwd_fused_wgs": (_i, [_i, _AP, _i]),
+    "segmi_fused_timeouts": (C.c_uint, [_i]),
+    "segmi_fused_test_hook": (_i, [C.c_uint, _i]),
     "segmi_bn_act_bwd_apply": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _f, C.c_uint32, _P]),
     "segmi_bn_act_bwd_apply_conv_ok": (_i, [_i, _AP, _AP, _AP, _AP]),
     "segmi_bn_act_bwd_apply_conv": (_i, [_i, _AP, _AP, _AP, _P, _P, _P, _P, _P, _P, _AP, _P, _P]),
-    "segmi_wgrad_set_cus": (_i, [_i]),
+    "segmi_wgrad_cus": (_i, [_i]),
     "segmi_add": (_i, [_i, _AP, _AP, _AP, _P]),
     "segmi_cast_copy": (_i, [_i, _AP, _i, _AP, _P]),
     "segmi_nchw_to_ndhwc": (_i, [_P, _i, _AP, _P]),

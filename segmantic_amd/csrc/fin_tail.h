@@ -57,11 +57,16 @@ static inline size_t fin_tail_arm(P& p, dim3 grid, int threads, int width, size_
 // of workgroups of a convolution that is streaming its output through that L2, it costs ~80 us per
 // launch (measured: 9.3 vs 6.5 ms per training step).  Instead the few floats that have to cross
 // XCDs are moved with agent-scope relaxed atomics -- write-through stores (sc1) and coherent loads
-// -- and ordered by hand: every thread waits for its own stores (workgroup-scope release = s_waitcnt
-// vmcnt(0)), the workgroup barrier collects the waves, one thread takes the ticket.
+// -- and ordered by hand: every thread waits for its own stores with an EXPLICIT `s_waitcnt vmcnt(0)`
+// (fin_drain_stores; a workgroup-scope release fence emits no VMEM wait on gfx950 -- rounds 2-3 had that wait
+// only because kernarg_late() happened to compile to a waited global_load), the workgroup barrier
+// collects the waves, one thread takes the ticket.
 __device__ __forceinline__ void fin_store(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// every storing wave, after its fin_store()s and before the barrier in front of the ticket / flag: inline asm, so
+// that no compiler pass can drop or move it (MI355X_MICROARCH.md, "Compiler hazard")
+__device__ __forceinline__ void fin_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float fin_load1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -91,7 +96,7 @@ __device__ __forceinline__ bool fin_tail_run(const float* __restrict__ partials,
   if (!ft.on) return false;
   __shared__ int s_fin_last;
   const int tid = threadIdx.x;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's row stores have completed
+  fin_drain_stores();                                        // this thread's row stores have completed
   __syncthreads();
   if (tid == 0) {
     const unsigned prev = __hip_atomic_fetch_add(&g_fin_tickets[ft.ticket], 1u, __ATOMIC_RELAXED,

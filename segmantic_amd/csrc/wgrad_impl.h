@@ -366,19 +366,20 @@ static inline bool wgrad_ws_cfg_ok(int stride, int ct) {
   (void)stride;
   return ct == 11 || ct == 21;
 }
-// CUs the weight-gradient kernels size their grids for (segmi_wgrad_set_cus; SEGMI_WGRAD_CUS overrides).  These
+// CUs the weight-gradient kernels size their grids for (the `cus` argument of segmi_conv3d_wgrad and of its
+// workspace query; SEGMI_WGRAD_CUS overrides).  These
 // kernels hold a CU exclusively (one 768-thread or 400-register workgroup per CU), so with one workgroup on
 // EVERY CU the dependent chain of the main stream gets no CU until they retire; sized for half the chip the two
 // streams really run side by side (5.55 -> 5.28 ms per training step, round 3).
-int wgrad_cus();
-static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride) {
+int wgrad_cus(int cus);
+static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus) {
   static const bool enabled = !(getenv("SEGMI_WGRAD_WS") && atoi(getenv("SEGMI_WGRAD_WS")) == 0);
   if (!enabled || dtype != SEGMI_BF16 || ksize != 3) return 0;
   const int ct = wgrad_ct(dtype, x->c, dy->c);
   if (!wgrad_ws_cfg_ok(stride, ct)) return 0;
   const int cto = ct / 10, cti = ct % 10;
   const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
-  int gx = wgrad_cus() / chunks / 8 * 8;        // one 768-thread workgroup per CU, a multiple of the 8 XCDs
+  int gx = wgrad_cus(cus) / chunks / 8 * 8;        // one 768-thread workgroup per CU, a multiple of the 8 XCDs
   if (gx < 8) return 0;
   // the tile shapes of launch_wgrad_ws (must match)
   const bool wide = dy->w > 8;
@@ -390,8 +391,8 @@ static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy
   if (act_voxels(x) * x->ld * 2 >= 0xfff00000ll || act_voxels(dy) * dy->ld * 2 >= 0xfff00000ll) return 0;
   return nt >= 4 * (int64_t)gx ? gx : 0;
 }
-static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride) {
-  const int ws = wgrad_ws_gx(dtype, x, dy, ksize, stride);
+static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus_arg) {
+  const int ws = wgrad_ws_gx(dtype, x, dy, ksize, stride, cus_arg);
   if (ws > 0) return ws;
   const int ct = wgrad_ct(dtype, x->c, dy->c);
   const int cto = ct / 10, cti = ct % 10;
@@ -400,7 +401,7 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
   // tile (200-400 VGPRs, 55-110 KB slabs).  Measured on MI355X: 1x1 blocks
   // 704/508/540/608 us at 256/512/1024/2048 workgroups, 2x2 blocks 125/198/348 us at 256/512/1024.
   static const int mfma_env = getenv("SEGMI_WGRAD_CUS_MFMA") ? atoi(getenv("SEGMI_WGRAD_CUS_MFMA")) / 8 * 8 : 0;   // experiments
-  const int cus = mfma_env >= 8 ? mfma_env : wgrad_cus();
+  const int cus = mfma_env >= 8 ? mfma_env : wgrad_cus(cus_arg);
   const int target = cto * cti == 1 ? 2 * cus : cus;
   int gx = target / chunks;
   if (gx < 1) gx = 1;

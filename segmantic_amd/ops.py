@@ -194,10 +194,10 @@ def conv3d_bn_bwd_sums_ok(x, y, ksize, stride) -> bool:
     return bool(lib.segmi_conv3d_bn_bwd_sums_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
 
 
-def wgrad_set_cus(cus: int) -> int:
-    """compute units the weight-gradient kernels size their grids for (segmi_wgrad_set_cus); returns the
-    previous value"""
-    return int(lib.segmi_wgrad_set_cus(int(cus)))
+def wgrad_cus(cus: int) -> int:
+    """compute units a weight-gradient call with the argument ``cus`` sizes its grid for (segmi_wgrad_cus:
+    a multiple of 8 in [8, 256]; <= 0 = the whole chip; SEGMI_WGRAD_CUS overrides)"""
+    return int(lib.segmi_wgrad_cus(int(cus)))
 
 
 def cu_masked_stream(cus_enabled: int, device=None) -> "torch.cuda.Stream":
@@ -315,16 +315,18 @@ def convT3d_fwd(x, y, packed, w_src, bias, prelu_alpha=None, residual=None, stat
                                 _ptr(stats), _bn_fin(stats_fin), _stream()), "convT3d_fwd")
 
 
-def conv3d_wgrad_workspace(x, dy, ksize, stride) -> int:
+def conv3d_wgrad_workspace(x, dy, ksize, stride, cus: int = 0) -> int:
+    """``cus``: the compute-unit budget the call will be made with (it sizes the partial slabs)"""
     ax, ay = act(x), act(dy)
     return int(lib.segmi_conv3d_wgrad_workspace(dtype_code(x), C.byref(ax), C.byref(ay), ksize,
-                                                stride))
+                                                stride, int(cus)))
 
 
-def conv3d_wgrad(x, dy, dw, db, ksize, stride, workspace, in_tf=None) -> None:
+def conv3d_wgrad(x, dy, dw, db, ksize, stride, workspace, in_tf=None, cus: int = 0) -> None:
+    """``cus``: compute units the kernel sizes its grid for (0 = the whole chip); per call, no global state"""
     ax, ay = act(x), act(dy)
     check(lib.segmi_conv3d_wgrad(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(dw), _ptr(db),
-                                 ksize, stride, _ptr(workspace), _in_affine(in_tf), _stream()),
+                                 ksize, stride, _ptr(workspace), _in_affine(in_tf), int(cus), _stream()),
           "conv3d_wgrad")
 
 
@@ -395,14 +397,45 @@ def bn_act_bwd_fused_rows(x) -> int:
     return int(lib.segmi_bn_act_bwd_fused_rows(C.byref(a)))
 
 
-def bn_act_bwd_fused(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, partials, fin) -> None:
+def bn_act_bwd_fused(dy, x, dx, mean, invstd, gamma, beta, prelu_alpha, partials, fin, max_wgs: int = 0) -> None:
     """reduce + finalise + apply of the BatchNorm / PReLU backward in one launch (small tensors);
-    ``fin`` = (count, dgamma, dbeta, dalpha, coef)"""
+    ``fin`` = (count, dgamma, dbeta, dalpha, coef); ``max_wgs``: the most workgroups (= whole CUs) the launch
+    may hold while its hand-off completes (0 = what the device holds at once)"""
     ady, ax, adx = act(dy), act(x), act(dx)
     bf = _bn_bwd_fin(fin)
     check(lib.segmi_bn_act_bwd_fused(dtype_code(x), C.byref(ady), C.byref(ax), C.byref(adx), _ptr(mean),
                                      _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(prelu_alpha), _ptr(partials),
-                                     C.byref(bf), _stream()), "bn_act_bwd_fused")
+                                     C.byref(bf), int(max_wgs), _stream()), "bn_act_bwd_fused")
+
+
+def bn_act_bwd_fused_wgs(x, max_wgs: int = 0) -> int:
+    """workgroups ``bn_act_bwd_fused`` would launch for ``x`` under ``max_wgs`` on the current device"""
+    a = act(x)
+    return int(lib.segmi_bn_act_bwd_fused_wgs(dtype_code(x), C.byref(a), int(max_wgs)))
+
+
+def fused_timeouts(reset: bool = False) -> int:
+    """expiries of ``bn_act_bwd_fused``'s bounded hand-off wait so far (host-visible counter, no device sync).
+    Non-zero: some launch wrote NaN gradients instead of hanging -- see ``check_fused_timeouts``."""
+    return int(lib.segmi_fused_timeouts(1 if reset else 0))
+
+
+def check_fused_timeouts(where: str = "") -> None:
+    """raise (and clear the counter) when a one-launch BatchNorm backward gave up waiting: its gradients are NaN, and
+    every optimiser step since has poisoned the weights -- the reference stops on a non-finite loss
+    (monai_unet.py:512-518); here the failure is an exception instead of a silent NaN run"""
+    n = fused_timeouts(reset=True)
+    if n:
+        raise RuntimeError(
+            f"{n} workgroup(s) of segmi_bn_act_bwd_fused gave up waiting for their launch's last workgroup"
+            f"{' (' + where + ')' if where else ''}: the launch was never fully resident (GPU shared with another "
+            "process, or CUs masked).  The gradients of that step are NaN and the weights are poisoned: restart "
+            "from the last checkpoint with SEGMI_FUSE_BN_BWD_SMALL=0 (three launches, no grid-wide wait).")
+
+
+def fused_test_hook(poll_limit: int = 0, no_publish: bool = False) -> None:
+    """tests only: poll bound of the hand-off wait (0 = default) / withhold the flag so every waiter expires"""
+    check(lib.segmi_fused_test_hook(int(poll_limit), 1 if no_publish else 0), "fused_test_hook")
 
 
 def bn_act_bwd_apply_conv_ok(dy, x, dx, out) -> bool:

@@ -306,8 +306,6 @@ class UNetEngine:
         self._saved: Dict[str, torch.Tensor] = {}
         self.timings: Dict[str, list] = {}
         self._carry_convs: set = set()
-        # weight-gradient kernels beside the main chain: grids sized for half the chip (see wgrad_cus_overlap)
-        ops.wgrad_set_cus(self.wgrad_cus_overlap if self.overlap_wgrad else 0)
         self.fixed_slope = torch.full((1,), FIXED_SLOPE.get(params.act, 0.0), dtype=torch.float32,
                                       device=self.device)
         self._build_arena()
@@ -680,19 +678,22 @@ class UNetEngine:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
+        # beside the main chain the kernels size their grids for part of the chip (wgrad_cus_overlap); a per-call
+        # argument of the C-ABI, so engines with different schedules do not interfere
+        cus = self.wgrad_cus_overlap if side is not None else 0
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             if conv.transposed:
                 # dW_T[ci][co][tap]: stride-2 conv wgrad with x := dy (fine), dy := x (coarse)
-                nbytes = ops.conv3d_wgrad_workspace(dy, x, 3, 2)
+                nbytes = ops.conv3d_wgrad_workspace(dy, x, 3, 2, cus)
                 ws = self._scratch_buf("wgrad", nbytes)
-                self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, dy, x, conv.gw, None, 3, 2, ws)
+                self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, dy, x, conv.gw, None, 3, 2, ws, cus=cus)
                 if need_bias:
                     ops.bias_grad(dy, conv.gb, ws)
             else:
-                nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride)
+                nbytes = ops.conv3d_wgrad_workspace(x, dy, conv.k, conv.stride, cus)
                 ws = self._scratch_buf("wgrad", nbytes)
                 self._timed(conv.prefix + ":wgrad", ops.conv3d_wgrad, x, dy, conv.gw,
-                            conv.gb if need_bias else None, conv.k, conv.stride, ws, in_tf=in_tf)
+                            conv.gb if need_bias else None, conv.k, conv.stride, ws, in_tf=in_tf, cus=cus)
 
     def _bsum_ok(self, conv: _Conv, dy, dx, bn: Optional["_BN"]) -> bool:
         """the BatchNorm-backward reduction of `bn` (whose output gradient is dx = dgrad(conv, dy)) can
@@ -740,9 +741,12 @@ class UNetEngine:
         if (not sums_rows and self.fuse_bn_bwd_small and self.fuse_fin and self.dropout_p <= 0.0
                 and ops.bn_act_bwd_fused_ok(dy, x_raw, dx)):
             # deep levels: reduce + finalise + apply as ONE launch (csrc/norm_act.hip, bn_act_bwd_fused_kernel)
+            # its workgroups hold a CU each and wait on it for the launch's last one: beside the CU-exclusive
+            # weight-gradient kernels of the second stream the grid is capped at the CUs those leave free, so no
+            # workgroup of this launch waits for one of them to retire (fused_bn_max_wgs)
             rows = ops.bn_act_bwd_fused_rows(x_raw)
             ops.bn_act_bwd_fused(dy, x_raw, dx, bn.mean, bn.invstd, bn.gamma, bn.beta, bn.alpha,
-                                 self._fstat(rows, bn.c), self._bwd_fin(bn, x_raw))
+                                 self._fstat(rows, bn.c), self._bwd_fin(bn, x_raw), max_wgs=self.fused_bn_max_wgs())
             return False
         if sums_rows:
             rows = sums_rows
@@ -1278,7 +1282,7 @@ class UNetEngine:
     overlap_wgrad = os.environ.get("SEGMI_SERIAL", "0") != "1"
     _side = None
     # CUs the weight-gradient kernels size their grids for while they run on the side stream
-    # (segmi_wgrad_set_cus; SEGMI_WGRAD_CUS overrides).  Their workgroups hold a CU exclusively (768 threads
+    # (the `cus` argument of segmi_conv3d_wgrad; SEGMI_WGRAD_CUS overrides).  Their workgroups hold a CU exclusively (768 threads
     # or ~400 registers each): one per CU on all 256 and the main chain's kernels wait for a CU to retire --
     # "overlap" was then mostly alternation.  Sized for half the chip both streams run: 5.55 -> 5.28 ms per
     # step (160: 5.40, 96: 5.53, 64: 5.93; `gpurun_out/r3/wcus_ab2.txt`).  Round 2 measured the same knob
@@ -1310,6 +1314,14 @@ class UNetEngine:
     # BatchNorm / PReLU backward of the small (<= 32 MB) tensors as one launch with a grid-wide hand-off
     # instead of reduce -> apply (SEGMI_FUSE_BN_BWD_SMALL=0: two launches)
     fuse_bn_bwd_small = os.environ.get("SEGMI_FUSE_BN_BWD_SMALL", "1") != "0"
+    _fused_wgs_env = int(os.environ.get("SEGMI_FUSED_BN_WGS", "-1"))      # A/B: -1 = derive from the schedule
+
+    def fused_bn_max_wgs(self) -> int:
+        """workgroups the one-launch BatchNorm backward may hold: the CUs the weight-gradient stream's budget
+        leaves free (0 = the device's capacity when nothing CU-exclusive runs beside it)"""
+        if self._fused_wgs_env >= 0:
+            return self._fused_wgs_env
+        return max(8, 256 - ops.wgrad_cus(self.wgrad_cus_overlap)) if self.overlap_wgrad else 0
     # BatchNorm-backward reduction in the epilogue of the input-gradient launch that produces its
     # operand (segmi_bn_bwd_sums); SEGMI_FUSE_BN_BWD=0 keeps the separate two-tensor pass (A/B)
     fuse_bn_bwd = os.environ.get("SEGMI_FUSE_BN_BWD", "1") != "0"

@@ -927,6 +927,62 @@ def test_deferred_and_fused_schedules_leave_bit_identical_gradients(size, batch)
     assert torch.equal(w0, w) and torch.equal(y0, y)
 
 
+def test_parameters_readers_wait_for_the_carried_update():
+    """the carried top-level update of a `training_step` runs on the weight-gradient stream AFTER the
+    call returns.  A reader of `net.parameters()` / `named_parameters()` on the caller's stream (gradient clipping,
+    EMA, logging) must be ordered behind it: a copy taken right after the step, with no synchronisation of the
+    caller's own, equals the weights after a full device sync -- also from a stream that is not the training one."""
+    K, size = 16, 128
+    img, lab = synthetic_batch(1, size, K, seed=7)
+    batch_d = {"image": img.to(DEV), "label": lab.to(DEV)}
+    _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
+    net.mixed_precision = True
+    net.train()
+    eng = net._engine_for(batch_d["image"])
+    assert eng.carry_top_wgrad and len(eng._carry_lvls) >= 1
+    net.training_step(batch_d)
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    for reader_stream in (torch.cuda.current_stream(), other):
+        net.training_step(batch_d)
+        with torch.cuda.stream(reader_stream):
+            early = torch.cat([p.detach().flatten() for p in net.parameters()]).clone()
+            early_named = {k: v.detach().clone() for k, v in net.named_parameters()}
+        torch.cuda.synchronize()
+        late = torch.cat([p.detach().flatten() for p in net.parameters()])
+        assert torch.equal(early, late)
+        assert all(torch.equal(v, dict(net.named_parameters())[k].detach()) for k, v in early_named.items())
+
+
+def test_training_step_raises_after_a_fused_bn_expiry():
+    """a NaN never silently enters a run.  With the test hook forcing the bounded wait of the
+    one-launch BatchNorm backward to expire, the step that follows raises (`check_fused_timeouts`) instead of
+    training on; with the hook off the same network steps normally again."""
+    from segmantic_amd import ops
+    K, size = 16, 32
+    img, lab = synthetic_batch(2, size, K, seed=8)
+    batch_d = {"image": img.to(DEV), "label": lab.to(DEV)}
+    _, net = pair(K, (16, 32, 64, 128, 256), (2, 2, 2, 2))
+    net.mixed_precision = True
+    net.train()
+    eng = net._engine_for(batch_d["image"])
+    if not eng.fuse_bn_bwd_small:
+        pytest.skip("one-launch BatchNorm backward switched off (SEGMI_FUSE_BN_BWD_SMALL=0)")
+    net.training_step(batch_d)
+    torch.cuda.synchronize()
+    ops.check_fused_timeouts("healthy step")
+    ops.fused_test_hook(poll_limit=64, no_publish=True)
+    try:
+        net.training_step(batch_d)
+        torch.cuda.synchronize()
+    finally:
+        ops.fused_test_hook()
+    assert ops.fused_timeouts() > 0
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        net.training_step(batch_d)
+    assert ops.fused_timeouts() == 0
+
+
 @pytest.mark.parametrize("vol,roi,overlap", [((96, 96, 96), 32, 0.5), ((72, 80, 88), 32, 0.25), ((64, 64, 70), 32, 0.5)])
 def test_windows_read_in_place_equal_gathered_windows(vol, roi, overlap, monkeypatch):
     """sliding-window driver, own network: the first-layer kernel reads the windows as views of the volume

@@ -4,6 +4,7 @@ f32 kernels are exact-f32 MFMA chains (only the summation order differs from one
 kernels are compared against the oracle evaluated on bf16-rounded inputs.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -424,10 +425,10 @@ def test_conv3d_wgrad(case, dtype):
 
 @pytest.mark.parametrize("case", [(16, 16, 3, 1, (32, 32, 32), 2), (32, 64, 3, 2, (16, 16, 16), 2)])
 def test_wgrad_grid_budget_changes_the_partition_not_the_gradient(case):
-    """segmi_wgrad_set_cus: the weight-gradient kernels size their grids (and their partial slabs) for that many
-    compute units -- the engine gives them half the chip beside the main chain.  Any budget yields the gradient
-    of the torch reference (another partition of the same f32 sums); the call returns the previous value, 0
-    restores the default, values are clamped to multiples of 8 in [8, 256]."""
+    """The `cus` argument of segmi_conv3d_wgrad: the weight-gradient kernels size their grids (and their partial
+    slabs) for that many compute units -- the engine gives them half the chip beside the main chain.  Any budget
+    yields the gradient of the torch reference (another partition of the same f32 sums); the budget is a per-call
+    argument (no process-wide state), clamped to multiples of 8 in [8, 256], <= 0 = the whole chip."""
     cin, cout, k, s, sp, n = case
     dtype = torch.bfloat16
     x = rnd((n, cin) + sp, 131)
@@ -436,22 +437,21 @@ def test_wgrad_grid_budget_changes_the_partition_not_the_gradient(case):
     w0 = torch.zeros((cout, cin, k, k, k), requires_grad=True)
     F.conv3d(q(x, dtype), w0, None, stride=s, padding=(k - 1) // 2).backward(q(dy, dtype))
     xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
-    first = ops.wgrad_set_cus(0)
-    try:
-        assert ops.wgrad_set_cus(64) in (256, first) and ops.wgrad_set_cus(1000) == 64 and ops.wgrad_set_cus(3) == 256
-        assert ops.wgrad_set_cus(0) == 8
-        got = {}
-        for cus in (256, 128, 64, 8):
-            ops.wgrad_set_cus(cus)
-            dw = torch.full_like(w0, float("nan"), device=DEV)
-            ws = torch.empty(ops.conv3d_wgrad_workspace(xd, dyd, k, s), dtype=torch.uint8, device=DEV)
-            ops.conv3d_wgrad(xd, dyd, dw, None, k, s, ws)
-            torch.cuda.synchronize()
-            assert relerr(dw.cpu(), w0.grad) < 5e-5, cus
-            got[cus] = dw.cpu()
-        assert float((got[256] - got[64]).abs().max()) <= 1e-4 * float(got[256].abs().max())
-    finally:
-        ops.wgrad_set_cus(first if first != 256 else 0)
+    if "SEGMI_WGRAD_CUS" not in os.environ:
+        assert [ops.wgrad_cus(c) for c in (0, -5, 3, 64, 100, 1000)] == [256, 256, 8, 64, 96, 256]
+    got = {}
+    sizes = {}
+    for cus in (0, 128, 64, 8):
+        dw = torch.full_like(w0, float("nan"), device=DEV)
+        sizes[cus] = ops.conv3d_wgrad_workspace(xd, dyd, k, s, cus)
+        ws = torch.empty(sizes[cus], dtype=torch.uint8, device=DEV)
+        ops.conv3d_wgrad(xd, dyd, dw, None, k, s, ws, cus=cus)
+        torch.cuda.synchronize()
+        assert relerr(dw.cpu(), w0.grad) < 5e-5, cus
+        got[cus] = dw.cpu()
+    assert float((got[0] - got[64]).abs().max()) <= 1e-4 * float(got[0].abs().max())
+    if "SEGMI_WGRAD_CUS" not in os.environ:
+        assert sizes[8] < sizes[0]          # fewer slabs for a smaller budget
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -1513,6 +1513,76 @@ def test_bn_backward_as_one_launch_matches_the_three_calls(c, sp, n, with_alpha,
     # tensors beyond 32 MB are refused by the query
     big = torch.empty((8, 64, 64, 64, 16), dtype=torch.bfloat16, device=DEV)
     assert not ops.bn_act_bwd_fused_ok(big, big, big)
+
+
+@pytest.mark.parametrize("max_wgs", [128, 40, 1])
+def test_bn_backward_one_launch_under_a_workgroup_cap(max_wgs):
+    """`max_wgs` of segmi_bn_act_bwd_fused: the engine caps the launch at the CUs the weight-gradient stream leaves
+    free, so that every workgroup of the grid-wide hand-off is resident.  Any cap gives the sums of the three calls
+    (another partition of the rows) and a finite dx; the launch never exceeds the cap or the device's capacity."""
+    c, sp, n, dtype = 32, (32, 32, 32), 4, torch.bfloat16
+    x, dy = rnd((n, c) + sp, 71, 2.0), rnd((n, c) + sp, 72)
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    mean, invstd = (rnd((c,), 73) * 0.5).to(DEV), (rnd((c,), 74).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd((c,), 75) + 1.5).to(DEV), (rnd((c,), 76) * 0.3).to(DEV)
+    alpha = torch.full((1,), 0.25, device=DEV)
+    count = n * sp[0] * sp[1] * sp[2]
+    cap = ops.bn_act_bwd_fused_wgs(xd, 0)
+    assert 1 <= cap <= 256 and 1 <= ops.bn_act_bwd_fused_wgs(xd, max_wgs) <= min(max_wgs, cap)
+
+    def run(mw):
+        dg, db = torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
+        da, coef = torch.full((1,), float("nan"), device=DEV), torch.full((2, c), float("nan"), device=DEV)
+        part = torch.zeros((ops.bn_act_bwd_fused_rows(xd), 3, c), device=DEV)
+        dx = torch.full_like(xd, float("nan"))
+        ops.bn_act_bwd_fused(dyd, xd, dx, mean, invstd, gamma, beta, alpha, part, (count, dg, db, da, coef), max_wgs=mw)
+        torch.cuda.synchronize()
+        return dx, [dg, db, da, coef]
+
+    dx0, ref = run(0)
+    dx1, got = run(max_wgs)
+    for a, g_ in zip(ref, got):
+        assert bool(torch.isfinite(g_).all())
+        assert float((a - g_).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7
+    assert bool(torch.isfinite(dx1.float()).all())
+    assert float((dx0.float() - dx1.float()).abs().max()) <= 1e-2 * float(dx0.float().abs().max())
+    assert ops.fused_timeouts() == 0
+
+
+def test_bn_backward_one_launch_expiry_is_counted_and_raised():
+    """The bounded wait of the grid-wide hand-off: with the test hook withholding the flag and a
+    tiny poll bound every workgroup gives up -- the launch ENDS (no hang), dx is NaN (never a plausible wrong
+    gradient), the host-visible counter says how many workgroups expired, and `check_fused_timeouts` turns it into
+    an exception and clears it.  The next launch, hook off, is healthy again."""
+    c, sp, n, dtype = 32, (16, 16, 16), 2, torch.bfloat16
+    x, dy = rnd((n, c) + sp, 81, 2.0), rnd((n, c) + sp, 82)
+    xd, dyd = to_ndhwc(x, dtype), to_ndhwc(dy, dtype)
+    mean, invstd = (rnd((c,), 83) * 0.5).to(DEV), (rnd((c,), 84).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd((c,), 85) + 1.5).to(DEV), (rnd((c,), 86) * 0.3).to(DEV)
+    count = n * sp[0] * sp[1] * sp[2]
+
+    def run():
+        dg, db, coef = torch.zeros((c,), device=DEV), torch.zeros((c,), device=DEV), torch.zeros((2, c), device=DEV)
+        part = torch.zeros((ops.bn_act_bwd_fused_rows(xd), 3, c), device=DEV)
+        dx = torch.zeros_like(xd)
+        ops.bn_act_bwd_fused(dyd, xd, dx, mean, invstd, gamma, beta, None, part, (count, dg, db, None, coef))
+        torch.cuda.synchronize()
+        return dx
+
+    ops.fused_timeouts(reset=True)
+    wgs = ops.bn_act_bwd_fused_wgs(xd, 0)
+    ops.fused_test_hook(poll_limit=64, no_publish=True)
+    try:
+        dx = run()
+    finally:
+        ops.fused_test_hook()
+    assert bool(torch.isnan(dx.float()).all())
+    assert ops.fused_timeouts() == wgs
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        ops.check_fused_timeouts("test")
+    assert ops.fused_timeouts() == 0
+    assert bool(torch.isfinite(run().float()).all())
+    ops.check_fused_timeouts("test")
 
 
 @pytest.mark.parametrize("n,sp,cout,with_alpha,with_affine", [(2, (32, 32, 32), 32, True, True),
