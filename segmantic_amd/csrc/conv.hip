@@ -238,9 +238,14 @@ const char* segmi_conv3d_fwd_kernel_name(int dtype, const segmi_act* in, const s
   const char* dt = dtype == SEGMI_BF16 ? "bf16" : "f32";
   if (mfma_ok(in->c, out->c)) {
     const int ck = pick_ck(dtype, in->c);
-    if (conv_ring_ok(dtype, in->c, ksize, stride, out))
-      snprintf(buf, sizeof buf, "conv_ring2_kernel<%s, CK=%d, NT=%d>", dt, ck,
-               ck == 32 && (out->c / 16) % 2 == 0 ? 2 : 1);
+    if (conv_ring_ok(dtype, in->c, ksize, stride, out)) {
+      if (conv_ring3_shape_ok(in->c, out->c, in->data, in->d, in->h, in->w, in->ld, out->d, out->h, out->w, out->ld,
+                              out->ld, out->ld))
+        snprintf(buf, sizeof buf, "conv_ring3_kernel<%s, CK=16> (LDS-DMA ring)", dt);
+      else
+        snprintf(buf, sizeof buf, "conv_ring2_kernel<%s, CK=%d, NT=%d>", dt, ck,
+                 ck == 32 && (out->c / 16) % 2 == 0 ? 2 : 1);
+    }
     else if (conv_ks_ok(dtype, in->c, ksize, stride))
       snprintf(buf, sizeof buf, "conv_fwd_ks_kernel<%s, k%d s%d>", dt, ksize, stride);
     else

@@ -1440,10 +1440,10 @@ def test_ring_kernel_predicates_refuse_samples_beyond_its_32_bit_addressing():
     that must be routed to the 64-bit kernels by EVERY predicate (not fail in the launcher)."""
     ok = torch.empty((1, 128, 128, 128, 16), dtype=torch.bfloat16, device=DEV)
     assert ops.conv3d_in_affine_ok(ok, ok, 3, 1) and ops.conv3d_bn_bwd_sums_ok(ok, ok, 3, 1)
-    assert "ring2" in ops.conv3d_fwd_kernel_name(ok, ok, 3, 1)
+    assert "ring" in ops.conv3d_fwd_kernel_name(ok, ok, 3, 1)
     big = torch.empty((1, 416, 416, 416, 16), dtype=torch.bfloat16, device=DEV)     # 2.3 GB, one sample
     assert not ops.conv3d_in_affine_ok(big, big, 3, 1) and not ops.conv3d_bn_bwd_sums_ok(big, big, 3, 1)
-    assert "ring2" not in ops.conv3d_fwd_kernel_name(big, big, 3, 1)
+    assert "ring" not in ops.conv3d_fwd_kernel_name(big, big, 3, 1)
     # and the layer still runs (a thin slab of it: the tile kernel), with statistics rows that match its kernel
     del big
     x = to_ndhwc(rnd((1, 16, 4, 416, 416), 5), torch.bfloat16)
