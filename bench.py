@@ -187,13 +187,24 @@ def roofline_of_top_conv(eng, key, voxels, precision, x_like, full_only=False):
     gbps = abytes / (avg * 1e-3) / 1e9
     ach = flops / (avg * 1e-3) / 1e12
     name = ops.conv3d_fwd_kernel_name(x_like, x_like, conv.k, conv.stride) if conv.cin == conv.cout else "?"
-    return {"kernel": f"segmi::{name} -- MONAI layer model.{conv.prefix}: {conv.cin}->{conv.cout} k{conv.k} conv at "
-                      f"full resolution, forward launch (identity residual from the LDS ring)",
-            "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    what = (f"segmi::{name} -- MONAI layer model.{conv.prefix}: {conv.cin}->{conv.cout} k{conv.k} conv at "
+            f"full resolution, forward launch (identity residual from the LDS ring)")
+    mfma = {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
+            "peak_TFLOPs": MFMA_PEAK_TFLOPS[precision], "frac": ach / MFMA_PEAK_TFLOPS[precision]}
+    hbm = {"algorithmic_bytes_per_launch": abytes, "achieved_GBps": gbps, "peak_GBps": HBM_PEAK_GBPS,
+           "frac": gbps / HBM_PEAK_GBPS}
+    intensity = flops / abytes
+    ridge = MFMA_PEAK_TFLOPS[precision] * 1e12 / (HBM_PEAK_GBPS * 1e9)
+    if intensity > ridge:
+        # above the chip ridge (the 32 -> 32 layers of a K = 32 network: 432 FLOP/B against ~310): the matrix
+        # pipe is the roof
+        return {"kernel": what, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[precision],
+                "unit": "TFLOP/s", "frac": mfma["frac"], "traffic": None, "avg_launch_ms": avg, "launches": len(ms),
+                "algorithmic_flops_per_launch": flops, "intensity_flop_per_byte": intensity, "hbm_view": hbm}
+    return {"kernel": what, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
             "avg_launch_ms": avg, "launches": len(ms), "algorithmic_bytes_per_launch": abytes,
-            "mfma_view": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": ach,
-                          "peak_TFLOPs": MFMA_PEAK_TFLOPS[precision], "frac": ach / MFMA_PEAK_TFLOPS[precision]}}
+            "mfma_view": mfma}
 
 
 def unet_conv_flops_per_voxel(channels, strides, cin, K, train: bool) -> float:
@@ -549,6 +560,31 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             out["f32_parity_mode"] = {"error": repr(e)}
+    if wl == "all":
+        # BASELINE config 4's per-GPU workload (160^3 patches, 32 labels; its 8-rank gradient exchange is the
+        # driver's --gpus 8 run): the largest batch <= the reference's 8 that fits this GPU
+        c4 = None
+        for b4 in (8, 4, 2, 1):
+            a4 = argparse.Namespace(**vars(args))
+            a4.batch, a4.size, a4.classes = b4, 160, 32
+            try:
+                r = run_train(a4, "bf16", rank, world, device, barrier, max(3, args.steps // 2), 2)
+                n = max(3, args.steps // 2)
+                c4 = {"what": f"BASELINE config 4 on one GPU: training_step, batch {b4} x 1ch x 160^3, 32 labels, bf16 "
+                              "(the 32-channel full-resolution layers; K padded to 32 = no padding)",
+                      "value": r["units"] / r["dt"], "unit": "voxels/s", "ms_per_step": r["dt"] / n * 1e3, "steps": n,
+                      "batch": b4, "dtype": "bf16", "step_conv_TFLOPs": r["step_conv_flops"] / 1e12,
+                      "whole_step_TFLOP_per_s": r["step_conv_flops"] / (r["dt"] / n) / 1e12, "roofline": r["roofline"]}
+                del r
+                torch.cuda.empty_cache()
+                break
+            except torch.OutOfMemoryError as e:
+                c4 = {"error": f"batch {b4}: {e!r}"[:300]}
+                torch.cuda.empty_cache()
+            except Exception as e:
+                c4 = {"error": repr(e)[:300]}
+                break
+        out["c4"] = c4
     if wl in ("all", "fit"):
         try:
             r = run_fit(args, rank, device, barrier, args.steps, args.warmup)

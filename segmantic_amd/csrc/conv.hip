@@ -239,7 +239,7 @@ const char* segmi_conv3d_fwd_kernel_name(int dtype, const segmi_act* in, const s
   if (mfma_ok(in->c, out->c)) {
     const int ck = pick_ck(dtype, in->c);
     if (conv_ring_ok(dtype, in->c, ksize, stride, out)) {
-      if (conv_ring3_shape_ok(in->c, out->c, in->data, in->d, in->h, in->w, in->ld, out->d, out->h, out->w, out->ld,
+      if (conv_ring3_shape_ok(in->c, out->c, in->data, out->data, in->d, in->h, in->w, in->ld, out->d, out->h, out->w, out->ld,
                               out->ld, out->ld))
         snprintf(buf, sizeof buf, "conv_ring3_kernel<%s, CK=16> (LDS-DMA ring)", dt);
       else

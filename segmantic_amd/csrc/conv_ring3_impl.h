@@ -2,9 +2,7 @@
 // bf16 16 -> 16 k3 s1 layers: the full-resolution convolution of the decoder (forward, input gradient, input
 // gradient + BatchNorm-backward sums) and the 16-channel layers at 64^3.  Same tiling and MFMA loop as ring2 (a
 // workgroup = an (8 x 16)-voxel column marching z, 4 planes per step; a wave = 2 rows x 4 planes, weights in
-// registers, one voxel fragment feeding the kd = 0, 1, 2 taps of three output planes).  What changed, and why
-// (4.9 vector instructions per MFMA, memory phases ADDING to the MFMA phase, 0.43 of HBM for
-// three rounds):
+// registers, one voxel fragment feeding the kd = 0, 1, 2 taps of three output planes).  What changed against ring2:
 //
 //  * Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane, gfx950): the planes of step k + 1 go from
 //    HBM straight into the ring while step k computes.  No staging registers (ring2 held 32 VGPRs across the MFMA
@@ -13,8 +11,8 @@
 //    the DMA write ZEROS to its LDS slot (scripts/probes/ldsdma_oob_probe.hip: out-of-range lanes write 0, and
 //    soffset takes part in the range check).  The DMA is issued from inline asm: hipcc orders every later ds_read
 //    behind a pending LDS-DMA it can see (vmcnt(0) in front of the MFMA loop); hidden from it, the DMA is ordered
-//    by hand -- each wave's counted `s_waitcnt vmcnt(N)` (N = the output stores issued after it) + the step's
-//    barrier.
+//    by hand -- vmcnt counts a wave's vector-memory operations in issue order, so "my pieces have landed" is
+//    `s_waitcnt vmcnt(8)` (8 = the output stores the wave issued after them), then the step's barrier.
 //  * The ring is 3 GROUPS of 4 contiguous planes (+ a 512-byte pad that takes the tail lanes of the 23rd 1-KiB
 //    piece): the 1440 16-byte chunks of a step are 22.5 wave-pieces, 6 per wave, instead of ring2's 8 loads per
 //    thread of which 30 % were idle slots.  Step k reads the last two planes of group k - 1 and the four of group
@@ -24,17 +22,21 @@
 //  * The input transform (segmi_in_affine: the producer's BatchNorm-apply + PReLU) runs IN PLACE on the landed
 //    group: every thread reads back the chunks its own lanes fetched (its own vmcnt orders that, no barrier),
 //    transforms and writes them back; padding chunks are redirected to a dump slot (border workgroups only).
-//  * Epilogue: an identity residual (out = conv(x) + x, the top unit) is ONE MORE K-SLOT of the MFMA chain -- ring2 padded
-//    its 9 taps to 10 half-k-steps with a zero weight; here that slot holds the 16 x 16 identity against the
-//    centre voxel, so the residual costs no instruction at all (exact: 1.0 * bf16 accumulates in f32) -- and the
-//    stores address with a per-lane offset computed once + the plane offset as the instruction's scalar soffset:
-//    2 conversions + 1 store per output tile.
+//  * Stores address with a per-lane offset computed once + the plane offset as the instruction's scalar soffset.
+//
+// What it is bound by (round 4, scripts/ring3_diag.py with SEGMI_RING3_DBG; 8 x 128^3 x 16, cold, alone): full 303 us;
+// MFMA loop off 288; staging DMA alone 176 (3.1 TB/s of input), stores alone 125 (4.3 TB/s), both 289: the memory
+// phases ADD and the MFMA loop (183 us alone) hides under them -- the launch is bound by what each CU pulls through its
+// vector-memory pipe (~17-20 GB/s per CU here, 23 in an element-wise kernel), L2-side bytes, the 1.41x halo of the
+// 8 x 16 tile included: 1.29 GB, i.e. ~220 us at the element-wise rate.  DESIGN.md section 6 lists the variants that
+// were built and measured on the way (all correct, none faster): a 6-pair ring of 2-plane steps with four pairs in
+// flight, an L2 warm-up two steps ahead, lane-contiguous 16-byte stores through an LDS transpose, and a 512-thread
+// producer / consumer form on 16 x 16 columns.
+// (A hazard met on the way: `buffer_store_dwordx4` with an SGPR soffset followed by a VALU write of its data
+// registers stored the NEW values in some lanes; hipcc pads that hazard only for stores without a register soffset.)
 //
 // Numerics: taps in ring2's (= every MFMA conv kernel's) k order, then + bias, then the residual: a layer gives the
-// same bits whichever kernel family its shape selects (eval outputs do not depend on the batch size or on the fused
-// decoder top, tests/test_e2e_gpu.py).  The one exception is the identity residual of the TRAINING forward of the top
-// unit (the launch with an input transform, which only this kernel computes): it enters the f32 chain behind the
-// centre plane's taps instead of being added last.
+// same bits whichever kernel family its shape selects.
 #pragma once
 #include "conv_ring_impl.h"
 
@@ -75,7 +77,7 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
   using G = Ring3Geom;
   using T = bf16_t;
-  constexpr int J = 5;                       // k-steps per kd (two taps per k-step, the 10th half = identity / zero)
+  constexpr int J = 5;                       // k-steps per kd (two taps per k-step, the 10th half-k-step is a zero weight)
   constexpr int NIT = 6 * J;
   constexpr unsigned kOob = 0x80000000u;     // + any soffset < 2^31: out of range, no 32-bit wrap
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,14 +106,10 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
   const T* resp = (const T*)p.res;
   // identity residual (out = conv(x) + x): the rows are the centre plane of the ring
   const bool res_in = resp && p.res == p.in && p.ldr == p.ldi && p.Cin == p.Cout;
-  // ... taken by the MFMA chain's spare k-slot: the training forward of the top unit (the launch with an input
-  // transform).  Eval forwards and input gradients keep "residual last", the order of the tile kernels and of
-  // dectop that compute the same layers at other shapes (bit-identical eval outputs whatever the batch / window).
-  const bool res_mfma = PLAIN && res_in && (p.dbg & 1) != 0;
   const bool res_ext = resp && !res_in;
 
   // ---- weights -> registers (gathered from the standard pack: tap T sits in k-step T/2 at lane group
-  // (T&1)*2 + (g&1)); the 10th half-k-step of kd = 1 is the identity when the residual rides in the chain
+  // (T&1)*2 + (g&1)); the 10th half-k-step is a zero weight
   frag_t wreg[3][J];
 #pragma unroll
   for (int kd = 0; kd < 3; ++kd)
@@ -124,12 +122,6 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
         const int sp = tap >> 1, gp = (tap & 1) * 2 + (g & 1);
         wreg[kd][j] = *reinterpret_cast<const frag_t*>(
             (const char*)p.wfrag + (((int64_t)sp * p.ntiles_total + nt0) * 64 + gp * 16 + r) * 16);
-      } else if (kd == 1 && res_mfma) {
-        // A[co = r][k = 8 (g&1) + e] = (co == ci): element e of this lane's fragment is 1.0 iff 8 (g&1) + e == r
-        const int e = r - 8 * (g & 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          wreg[kd][j][q] = e == 2 * q ? 0x00003F80u : (e == 2 * q + 1 ? 0x3F800000u : 0u);
       }
     }
   // per-lane part of the voxel-fragment address of k-step j (inside a plane, first row of the wave); the spare
@@ -138,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     int t9 = 2 * j + (g >> 1);
-    if (t9 > 8) t9 = 4;
+    if (t9 > 8) t9 = 8;
     lb[j] = ((t9 / 3) * G::HW + t9 % 3 + r) * G::ROWB + (g & 1) * 16 + wave * 2 * G::HW * G::ROWB;
   }
 
@@ -321,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
     const int zb = step * G::TD;
     const bool more = step + 1 < nsteps_z;
     // ---- the next group: planes z0 + zb + 5 .. + 8, straight into the ring
-    if (more) dma_group(g_next, z0 + zb + 5);
+    if (more && !(p.dbg & 2)) dma_group(g_next, z0 + zb + 5);
     // residual rows of this step's outputs (external residual: the gradient sums of the backward chain)
     typedef Raw4<T>::type raw4_t;
     raw4_t resv[4][2];
@@ -375,12 +367,12 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- the landed group's input transform, in place (each thread its own chunks: its own vmcnt orders it)
-    if (in_tf && more) {
+    if (in_tf && more && !(p.dbg & 16)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       transform_group(g_next, p.Di - (z0 + zb + 5));
     }
     // identity residual outside the chain (PReLU epilogues): the centre plane of the ring
-    if (res_in && !res_mfma) {
+    if (res_in) {
 #pragma unroll
       for (int zi = 0; zi < 4; ++zi)
 #pragma unroll
@@ -391,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
               smem + pb + ((2 * wave + ro + 1) * G::HW + r + 1) * G::ROWB + (4 * g) * (int)sizeof(T));
         }
     }
-    if (resp && !res_mfma) {
+    if (resp) {
 #pragma unroll
       for (int zi = 0; zi < 4; ++zi)
 #pragma unroll
@@ -432,11 +424,11 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : alpha * v[e];
           }
         }
-        if (resp && !res_mfma) v += Raw4<T>::cvt(resv[zi][ro]);
+        if (resp) v += Raw4<T>::cvt(resv[zi][ro]);
         u32x2 o;
         o[0] = pack_bf16x2(v[0], v[1]);
         o[1] = pack_bf16x2(v[2], v[3]);
-        __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, o_off[ro], opoff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, (p.dbg & 4) ? kOob : o_off[ro], opoff, 0);
         if constexpr (BSUM) {
           // the sums are taken of the STORED gradient (bf16-rounded), as the separate pass reads it
           f32x4 d = Raw4<T>::cvt(o);
@@ -509,15 +501,17 @@ __global__ __launch_bounds__(256, 2) void conv_ring3_kernel(ConvParams p) {
 }
 
 static inline bool conv_ring3_ok(const ConvParams& p) {
-  return conv_ring3_shape_ok(p.Cin, p.Cout, p.in, p.Di, p.Hi, p.Wi, p.ldi, p.Do, p.Ho, p.Wo, p.ldo, p.ldr, p.ldbx);
+  return conv_ring3_shape_ok(p.Cin, p.Cout, p.in, p.out, p.Di, p.Hi, p.Wi, p.ldi, p.Do, p.Ho, p.Wo, p.ldo, p.ldr, p.ldbx);
 }
 
 template <int MODE>
 static int launch_conv_ring3_k(ConvParams p, hipStream_t st) {
   using G = Ring3Geom;
   p.tz = conv_ring_zsplit(SEGMI_BF16, p.Cin, 3, 1, p.N, p.Do, p.Ho, p.Wo);
-  static const int reschain = getenv("SEGMI_RING3_RESCHAIN") ? atoi(getenv("SEGMI_RING3_RESCHAIN")) : 0;   // experiment
-  p.dbg = reschain ? 1 : 0;
+  // diagnostics (timing probes, WRONG results): SEGMI_RING3_DBG bits: 2 = no staging DMA in the step loop, 4 = stores
+  // dropped, 8 = no MFMA loop, 16 = no input transform
+  static const int dbg3 = getenv("SEGMI_RING3_DBG") ? atoi(getenv("SEGMI_RING3_DBG")) : 0;
+  p.dbg = dbg3;
   static const int xcd = getenv("SEGMI_RING2_XCD") ? atoi(getenv("SEGMI_RING2_XCD")) : 1;
   p.ty = cdiv(p.Ho, G::TH);
   p.tx = cdiv(p.Wo, G::TW);

@@ -80,16 +80,17 @@ static inline int conv_ring_zsplit(int dtype, int cin, int ksize, int stride, in
   return zs;
 }
 // ring3 (conv_ring3_impl.h: LDS-DMA staging) takes a ring layer when it has 16 input channels, 16-byte aligned
-// input rows, and every operand sample stays below 2^31 BYTES (its out-of-range marker 2^31 + a plane offset must
+// input and output rows, and every operand sample stays below 2^31 BYTES (its out-of-range marker 2^31 + a plane offset must
 // not wrap); ring2 takes the others.  SEGMI_RING3=0: ring2 everywhere (A/B).
-static inline bool conv_ring3_shape_ok(int cin, int cout, const void* in, int Di, int Hi, int Wi, int ldi, int Do,
+static inline bool conv_ring3_shape_ok(int cin, int cout, const void* in, const void* out, int Di, int Hi, int Wi, int ldi, int Do,
                                        int Ho, int Wo, int ldo, int ldr, int ldbx) {
   static const bool on = !(getenv("SEGMI_RING3") && atoi(getenv("SEGMI_RING3")) == 0);
   if (!on || cin != 16 || cout % 16 != 0) return false;
   const int64_t lim = 1ll << 31;
   return (int64_t)(Di + 8) * Hi * Wi * ldi * 2 < lim && (int64_t)(Do + 4) * Ho * Wo * ldo * 2 < lim &&
          (int64_t)(Do + 4) * Ho * Wo * (ldr > 0 ? ldr : 1) * 2 < lim &&
-         (int64_t)(Do + 4) * Ho * Wo * (ldbx > 0 ? ldbx : 1) * 2 < lim && ((uintptr_t)in % 16) == 0 && ldi % 8 == 0;
+         (int64_t)(Do + 4) * Ho * Wo * (ldbx > 0 ? ldbx : 1) * 2 < lim && ((uintptr_t)in % 16) == 0 && ldi % 8 == 0 &&
+         ((uintptr_t)out % 16) == 0 && ldo % 8 == 0;          // 16-byte DMA pieces and 16-byte stores
 }
 static inline bool conv_ring_ok(int dtype, int cin, int ksize, int stride, const segmi_act* out) {
   return conv_ring_zsplit(dtype, cin, ksize, stride, out->n, out->d, out->h, out->w) > 0;

@@ -1,5 +1,7 @@
 // sliding.hip -- sliding-window inference data movement (gather / ordered blend / finalise),
 // channel argmax, label overlap counts and the on-device patch cropper.  All HBM-bound.
+#include <type_traits>
+
 #include "common.h"
 
 namespace segmi {
@@ -356,6 +358,111 @@ static inline int grid_for(int64_t total) {
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+
+// The same blend for schedules in which at most TWO windows cover a coordinate in every dimension (overlap <= 0.5:
+// BASELINE config 3 and the reference's defaults): the <= 8 covering windows of a voxel are located first (z, y:
+// wave-uniform; x: per lane), all their loads are issued back to back with a non-temporal hint (each of the 23 GB of
+// predictions is read exactly once), then summed in ascending window order -- the same f32 sequence as
+// sw_blend_kernel, bit for bit.  sw_blend_kernel finds and loads its windows inside three nested loops with
+// per-lane conditions: hipcc keeps ONE 16-byte load per wave in flight, 32 KB per CU, and the pass streamed at
+// 2.9 TB/s (round 3: 8 ms of a 43 ms volume).
+template <typename T, typename L, int G>
+__global__ __launch_bounds__(256) void sw_blend2_kernel(
+    const T* __restrict__ cache, BlendSched sc, int lo, int hi, const float* __restrict__ imp,
+    float* __restrict__ out, float* __restrict__ cnt_out, L* __restrict__ labels, int D, int H,
+    int W, int K, int ldo, int rd, int rh, int rw, int ldp, int normalize) {
+  typedef typename std::conditional<G == 8, u32x4, f32x4>::type vec_t;
+  const int tpv = K / G;
+  const int lanes_row = W * tpv;
+  const int segs = (lanes_row + 255) / 256;
+  const int nseg = D * H * segs;
+  const int64_t wvox = (int64_t)rd * rh * rw;
+  for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const int seg = s % segs, row = s / segs;
+    const int y = row % H, z = row / H;
+    const int e = seg * 256 + (int)threadIdx.x;
+    const bool live = e < lanes_row;
+    const int x = live ? e / tpv : 0;
+    const int k = live ? (e % tpv) * G : 0;
+    const int64_t v = (int64_t)row * W + x;
+    // first covering window and how many cover (1 or 2), per dimension
+    int kz0 = 0, ky0 = 0;
+    while (kz0 + 1 < sc.n[0] && sc.start[0][kz0] + rd <= z) ++kz0;
+    while (ky0 + 1 < sc.n[1] && sc.start[1][ky0] + rh <= y) ++ky0;
+    const int nzc = kz0 + 1 < sc.n[0] && sc.start[0][kz0 + 1] <= z ? 2 : 1;
+    const int nyc = ky0 + 1 < sc.n[1] && sc.start[1][ky0 + 1] <= y ? 2 : 1;
+    int kx0 = 0, sx0 = sc.start[2][0], sx1 = sc.start[2][0];
+    bool two_x = false;
+    for (int kx = 1; kx < sc.n[2]; ++kx) {
+      const int st = sc.start[2][kx];
+      const bool past = sx0 + rw <= x;              // the current first window ends before x: move on
+      if (past) { kx0 = kx; sx0 = st; }
+      else if (!two_x && kx == kx0 + 1 && st <= x) { two_x = true; sx1 = st; }
+    }
+    const int lz0 = z - sc.start[0][kz0], ly0 = y - sc.start[1][ky0];
+    const int lz1 = nzc == 2 ? z - sc.start[0][kz0 + 1] : 0, ly1 = nyc == 2 ? y - sc.start[1][ky0 + 1] : 0;
+    vec_t pv[8];
+    float wt[8];
+    bool ok[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int iz = c >> 2, iy = (c >> 1) & 1, ix = c & 1;
+      const int w = ((kz0 + iz) * sc.n[1] + ky0 + iy) * sc.n[2] + kx0 + ix;
+      ok[c] = live && iz < nzc && iy < nyc && (ix == 0 || two_x) && w >= lo && w < hi;
+      const int lz = iz ? lz1 : lz0, ly = iy ? ly1 : ly0, lx = x - (ix ? sx1 : sx0);
+      const int64_t lv = ok[c] ? ((int64_t)lz * rh + ly) * rw + lx : 0;
+      const int64_t slot = ok[c] ? (int64_t)(w - lo) : 0;
+      pv[c] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(cache + (slot * wvox + lv) * ldp + k));
+      wt[c] = imp ? imp[lv] : 1.f;
+    }
+    float a[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) a[j] = 0.f;
+    float cacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (ok[c]) {
+        if constexpr (G == 8) {
+          const u32x4 o = pv[c];
+          a[0] += wt[c] * __uint_as_float(o[0] << 16); a[1] += wt[c] * __uint_as_float(o[0] & 0xffff0000u);
+          a[2] += wt[c] * __uint_as_float(o[1] << 16); a[3] += wt[c] * __uint_as_float(o[1] & 0xffff0000u);
+          a[4] += wt[c] * __uint_as_float(o[2] << 16); a[5] += wt[c] * __uint_as_float(o[2] & 0xffff0000u);
+          a[6] += wt[c] * __uint_as_float(o[3] << 16); a[7] += wt[c] * __uint_as_float(o[3] & 0xffff0000u);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += wt[c] * pv[c][j];
+        }
+        cacc += wt[c];
+      }
+    }
+    if (live) {
+      if (normalize) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) a[j] = a[j] / cacc;
+      }
+      if (out) {
+#pragma unroll
+        for (int j = 0; j < G; j += 4)
+          *reinterpret_cast<f32x4*>(out + v * ldo + k + j) = f32x4{a[j], a[j + 1], a[j + 2], a[j + 3]};
+      }
+      if (cnt_out && k == 0) cnt_out[v] = cacc;
+    }
+    if (labels) {
+      float bv = a[0];
+      int bi = k;
+#pragma unroll
+      for (int j = 1; j < G; ++j)
+        if (am_better(bv, bi, a[j], k + j)) { bv = a[j]; bi = k + j; }
+      for (int o = 1; o < tpv; o <<= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (am_better(bv, bi, ov, oi)) { bv = ov; bi = oi; }
+      }
+      if (live && k == 0) labels[v] = (L)bi;
+    }
+  }
+}
+
 }  // namespace segmi
 
 using namespace segmi;
@@ -540,10 +647,30 @@ int segmi_sw_blend(int dtype, const void* cache, int k, int ldp, const int32_t* 
   const int64_t row_segs = (int64_t)d * h * (((int64_t)w * (vec ? k / gfull : k) + 255) / 256);
   SEGMI_CHECK_ARG(row_segs < (1ll << 31) && (int64_t)w * k < (1ll << 30), "sw_blend: volume too large");
   const int grid = (int)(row_segs < 16384 ? row_segs : 16384);
+  // at most two windows cover any coordinate in every dimension (start[i + 2] >= start[i] + roi): the variant that
+  // issues all covering loads up front (SEGMI_SW_BLEND2=0: the generic kernel, for A/B)
+  static const bool blend2_on = !(getenv("SEGMI_SW_BLEND2") && atoi(getenv("SEGMI_SW_BLEND2")) == 0);
+  bool two = blend2_on;
+  {
+    const int nn[3] = {nz, ny, nx}, rr[3] = {rd, rh, rw};
+    for (int dd = 0; dd < 3 && two; ++dd)
+      for (int i = 0; i + 2 < nn[dd]; ++i)
+        if (sc.start[dd][i + 2] < sc.start[dd][i] + rr[dd]) { two = false; break; }
+    for (int dd = 0; dd < 3 && two; ++dd)          // ascending, gap-free coverage (MONAI's dense schedule)
+      for (int i = 0; i + 1 < nn[dd]; ++i)
+        if (sc.start[dd][i + 1] <= sc.start[dd][i] || sc.start[dd][i + 1] > sc.start[dd][i] + rr[dd]) { two = false; break; }
+  }
 #define BLEND(TT, LL, GG)                                                                         \
-  hipLaunchKernelGGL((sw_blend_kernel<TT, LL, GG>), grid, 256, 0, st, (const TT*)cache, sc, win_lo, \
-                     win_hi, importance, out_logits, out_count, (LL*)labels, d, h, w, k, ldo, rd, \
-                     rh, rw, ldp, normalize)
+  do {                                                                                            \
+    if (two)                                                                                      \
+      hipLaunchKernelGGL((sw_blend2_kernel<TT, LL, GG>), grid, 256, 0, st, (const TT*)cache, sc, win_lo, \
+                         win_hi, importance, out_logits, out_count, (LL*)labels, d, h, w, k, ldo, rd, \
+                         rh, rw, ldp, normalize);                                                 \
+    else                                                                                          \
+      hipLaunchKernelGGL((sw_blend_kernel<TT, LL, GG>), grid, 256, 0, st, (const TT*)cache, sc, win_lo, \
+                         win_hi, importance, out_logits, out_count, (LL*)labels, d, h, w, k, ldo, rd, \
+                         rh, rw, ldp, normalize);                                                 \
+  } while (0)
   if (vec) {
     if (dtype == SEGMI_BF16) {
       if (label_bytes == 1) BLEND(bf16_t, uint8_t, 8);
