@@ -560,6 +560,26 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             out["f32_parity_mode"] = {"error": repr(e)}
+    if wl in ("all", "fit"):
+        try:
+            r = run_fit(args, rank, device, barrier, args.steps, args.warmup)
+            dt = maxdt(r["dt"])
+            fit = {"what": f"training_step fed by the fit loop's on-GPU sampler (4 cached {r['volume']}^3 volumes, 2 volumes x "
+                           f"{args.batch // 2} label-class crops + flips per step) instead of a fixed batch",
+                   "value": r["units"] * world / dt, "unit": "voxels/s", "ms_per_step": dt / args.steps * 1e3,
+                   "steps": args.steps, "dtype": args.precision}
+            if wl == "fit":
+                out = {"metric": f"3D UNet fit (sampler + step) voxels/s on {args.size}^3 {args.precision}",
+                       "value": fit["value"], "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                       "warmup": args.warmup, "ms_per_step": fit["ms_per_step"], "higher_is_better": True,
+                       "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                       "config": {"workload": fit["what"], "parallelism": f"dp{world}"}}
+            else:
+                out["fit"] = fit
+        except Exception as e:
+            if wl == "fit":
+                raise
+            out["fit"] = {"error": repr(e)}
     if wl == "all":
         # BASELINE config 4's per-GPU workload (160^3 patches, 32 labels; its 8-rank gradient exchange is the
         # driver's --gpus 8 run): the largest batch <= the reference's 8 that fits this GPU
@@ -584,27 +604,7 @@ def main():
             except Exception as e:
                 c4 = {"error": repr(e)[:300]}
                 break
-        out["c4"] = c4
-    if wl in ("all", "fit"):
-        try:
-            r = run_fit(args, rank, device, barrier, args.steps, args.warmup)
-            dt = maxdt(r["dt"])
-            fit = {"what": f"training_step fed by the fit loop's on-GPU sampler (4 cached {r['volume']}^3 volumes, 2 volumes x "
-                           f"{args.batch // 2} label-class crops + flips per step) instead of a fixed batch",
-                   "value": r["units"] * world / dt, "unit": "voxels/s", "ms_per_step": dt / args.steps * 1e3,
-                   "steps": args.steps, "dtype": args.precision}
-            if wl == "fit":
-                out = {"metric": f"3D UNet fit (sampler + step) voxels/s on {args.size}^3 {args.precision}",
-                       "value": fit["value"], "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-                       "warmup": args.warmup, "ms_per_step": fit["ms_per_step"], "higher_is_better": True,
-                       "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-                       "config": {"workload": fit["what"], "parallelism": f"dp{world}"}}
-            else:
-                out["fit"] = fit
-        except Exception as e:
-            if wl == "fit":
-                raise
-            out["fit"] = {"error": repr(e)}
+        out["c4"] = c4      # after the fit leg: its 60+ GB of activations leave the allocator in a state the next leg pays for
     # CPU baselines LAST: the torch-CPU oracle leaves a 16-thread pool behind, and a GPU leg measured right
     # after it is host-bound (round 3: 168 ms instead of 8 ms to enqueue one volume's window groups, lane
     # busy times unchanged -- the driver's 17.5 vs the builder's 21.3 volumes/s of round 2); nothing that

@@ -512,10 +512,17 @@ static int launch_conv_ring3_k(ConvParams p, hipStream_t st) {
   // dropped, 8 = no MFMA loop, 16 = no input transform
   static const int dbg3 = getenv("SEGMI_RING3_DBG") ? atoi(getenv("SEGMI_RING3_DBG")) : 0;
   p.dbg = dbg3;
-  static const int xcd = getenv("SEGMI_RING2_XCD") ? atoi(getenv("SEGMI_RING2_XCD")) : 1;
+  // ring2's XCD-aware column map (XCD k walks the k-th eighth of the columns: neighbours' halos meet in one L2) is used
+  // for launches of at most one round of workgroups (<= 512: the 64^3 layers -- inference 41.4 vs 42.3 ms per volume
+  // with / without) and NOT for larger ones: on the full-resolution 8 x 128^3 launch (1024 workgroups, two rounds) it
+  // costs 10 % (0.300 -> 0.270 ms inside the training step, step 5.11 -> 5.02 ms, alternating runs; memory-only
+  // diagnostic 289 -> 228 us).  The halo re-reads it saves there were Infinity-Cache hits, and a CU's vector-memory
+  // pipe -- the bound of this kernel -- does not care where a line comes from.  SEGMI_RING3_XCD = 0 / 1 forces it.
+  static const int xcd_env = getenv("SEGMI_RING3_XCD") ? atoi(getenv("SEGMI_RING3_XCD")) : -1;
   p.ty = cdiv(p.Ho, G::TH);
   p.tx = cdiv(p.Wo, G::TW);
   dim3 grid((unsigned)(p.N * p.ty * p.tx * p.tz), (unsigned)(p.Cout / 16));
+  const int xcd = xcd_env >= 0 ? xcd_env : (grid.x <= 512 ? 1 : 0);
   p.xcd = xcd != 0 && grid.x % 8 == 0;
   constexpr bool kStats = (MODE & 2) != 0, kBsum = MODE == 4;
   p.fin_on = p.fin_on && (kStats || kBsum);

@@ -143,6 +143,47 @@ def test_bf16_path_close_to_f32_oracle(train):
         assert abs(float(res["loss"].cpu()) - float(ref_dice_loss(out_ref, lab))) < 2e-2
 
 
+@pytest.mark.parametrize("size", [64, 128])
+def test_bf16_training_forward_vs_oracle_at_benchmark_scale(size, record_property):
+    """the benchmarked bf16 path against the CPU oracle at BASELINE config 2's scale (one patch
+    of 64^3 / 128^3, 16 labels, training-mode BatchNorm): relative logit error, argmax agreement and loss deviation
+    are RECORDED (junit properties + stdout) and gated at the measured values + margin.  The oracle forward takes a
+    few seconds on the test box's host cores; the exact-f32 path is checked on the same input against the north_star
+    gate (1e-3 relative; asserted 3e-4)."""
+    k = 16
+    ref, net = build_pair(k, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2))
+    img, lab = synthetic_batch(1, size, k, seed=11)
+    ref.train()
+    with torch.no_grad():
+        out_ref = ref(img)
+    loss_ref = float(ref_dice_loss(out_ref, lab))
+    net.to(DEV).train()
+    # f32 storage, exact-f32 MFMA chains
+    with torch.no_grad():
+        out32 = net(img.to(DEV)).float().cpu()
+    e32 = rel(out32, out_ref)
+    # bf16 storage
+    net.mixed_precision = True
+    with torch.no_grad():
+        out16 = net(img.to(DEV)).float().cpu()
+    torch.cuda.synchronize()
+    e16 = rel(out16, out_ref)
+    agree = float((torch.argmax(out16, 1) == torch.argmax(out_ref, 1)).float().mean())
+    agree32 = float((torch.argmax(out32, 1) == torch.argmax(out_ref, 1)).float().mean())
+    res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
+    dl = abs(float(res["loss"].cpu()) - loss_ref) / abs(loss_ref)
+    print(f"\nbf16 vs oracle @ {size}^3: rel. logit error {e16:.3e}, argmax agreement {agree:.5f}, loss rel. dev. {dl:.2e}; "
+          f"f32: rel. error {e32:.2e}, argmax agreement {agree32:.6f}")
+    for name, v in (("bf16_rel_err", e16), ("bf16_argmax_agreement", agree), ("bf16_loss_rel_dev", dl),
+                    ("f32_rel_err", e32), ("f32_argmax_agreement", agree32)):
+        record_property(f"{name}_{size}", v)
+    assert e32 < 3e-4, e32
+    assert agree32 > 0.9995, agree32
+    assert e16 < 4e-2, e16
+    assert agree > 0.975, agree
+    assert dl < 1e-2, dl
+
+
 def test_autograd_bridge_matches_fused_step():
     ref, net = build_pair(3, 1, (16, 32, 64), (2, 2))
     img, lab = synthetic_batch(2, 32, 3, seed=7)
