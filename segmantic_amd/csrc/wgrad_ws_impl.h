@@ -72,7 +72,7 @@ __global__ __launch_bounds__(768) void wgrad_ws_kernel(WgradParams p) {
   const int cols = p.ty * p.tx;
   const int nunits = p.N * p.zs * cols;
   int u_begin, u_end, u_stride;
-  if ((nx & 7) == 0) {
+  if ((nx & 7) == 0 && !(p.dbg & 64)) {        // SEGMI_WGRAD_DBG bit 64: the plain unit order (A/B of the XCD grouping)
     const int xcd = bid & 7, slot = bid >> 3;
     u_begin = (int)((int64_t)nunits * xcd / 8) + slot;
     u_end = (int)((int64_t)nunits * (xcd + 1) / 8);

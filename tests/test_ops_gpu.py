@@ -206,6 +206,67 @@ def test_conv3d_epilogue_prelu_residual_and_views(dtype):
     assert float(big_out[..., :16].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,sp,mode", [(4, (18, 64, 120), "tf_identity"), (1, (64, 64, 128), "tf_identity"),
+                                       (4, (18, 64, 120), "alpha_res_stats"), (1, (62, 60, 128), "plain"),
+                                       (2, (33, 61, 125), "sums")])
+def test_conv_ring3_dma_ring_ragged_and_segmented_shapes(n, sp, mode):
+    """conv_ring3_kernel (LDS-DMA ring, round 4) away from the benchmark shape: extents that are not multiples of the
+    (4, 8, 16) step / tile (the zero fill of partial planes, rows and columns comes from the buffer range check, the
+    stores of lanes outside the tensor are dropped by it), z-split columns (several segments per column: the halo
+    planes of a segment are real data of its neighbour), the in-place input transform on border workgroups (padding
+    chunks must stay zero), every epilogue.  Against torch on the bf16-rounded operands."""
+    dtype = torch.bfloat16
+    c = 16
+    x, r = rnd((n, c) + sp, 521), rnd((n, c) + sp, 522)
+    w, b = rnd((c, c, 3, 3, 3), 523, 0.05), rnd((c,), 524, 0.1)
+    xd, rd = to_ndhwc(x, dtype), to_ndhwc(r, dtype)
+    yd = torch.full_like(xd, float("nan"))
+    assert "ring3" in ops.conv3d_fwd_kernel_name(xd, yd, 3, 1), ops.conv3d_fwd_kernel_name(xd, yd, 3, 1)
+    if mode == "tf_identity":
+        scale, shift = (rnd((c,), 525) * 0.3 + 1.0).to(DEV), (rnd((c,), 526) * 0.2).to(DEV)
+        alpha = torch.tensor([0.2], device=DEV)
+        t = q(x, dtype) * scale.cpu().view(1, -1, 1, 1, 1) + shift.cpu().view(1, -1, 1, 1, 1)
+        t = q(torch.where(t > 0, t, 0.2 * t), dtype)
+        ref = F.conv3d(t, q(w, dtype), b, padding=1) + t
+        ops.conv3d_fwd(xd, yd, ops.wpack(dtype, 0, w.to(DEV), c, c, 3), None, 0, b.to(DEV), 3, 1, residual=xd,
+                       in_tf=(scale, shift, alpha))
+    elif mode == "alpha_res_stats":
+        raw = F.conv3d(q(x, dtype), q(w, dtype), b, padding=1)
+        ref = F.prelu(raw, torch.tensor([0.3])) + q(r, dtype)
+        rows = ops.conv3d_stats_rows(xd, yd, 3, 1)
+        stats = torch.zeros((rows, 2, c), device=DEV)
+        ops.conv3d_fwd(xd, yd, ops.wpack(dtype, 0, w.to(DEV), c, c, 3), None, 0, b.to(DEV), 3, 1,
+                       prelu_alpha=torch.tensor([0.3], device=DEV), residual=rd, stats=stats)
+        torch.cuda.synchronize()
+        ssum, ssq = stats[:, 0].double().sum(0).cpu(), stats[:, 1].double().sum(0).cpu()
+        cnt = raw.numel() / c
+        assert float((ssum - raw.double().sum((0, 2, 3, 4))).abs().max()) / cnt < 2e-2 * float(raw.abs().max())
+        assert float((ssq - (raw.double() ** 2).sum((0, 2, 3, 4))).abs().max()) / cnt < 2e-2 * float(raw.abs().max()) ** 2
+    elif mode == "plain":
+        ref = F.conv3d(q(x, dtype), q(w, dtype), None, padding=1)
+        ops.conv3d_fwd(xd, yd, ops.wpack(dtype, 0, w.to(DEV), c, c, 3), None, 0, None, 3, 1)
+    else:       # input gradient + the BatchNorm-backward sums of the layer its output flows into
+        ref = F.conv_transpose3d(q(x, dtype), q(w, dtype), None, padding=1) + q(x, dtype)      # dgrad + identity residual
+        mean, invstd = (rnd((c,), 527) * 0.3).to(DEV), (rnd((c,), 528).abs() + 0.5).to(DEV)
+        gamma, beta = (rnd((c,), 529) + 1.5).to(DEV), (rnd((c,), 530) * 0.3).to(DEV)
+        rows = ops.conv3d_stats_rows(xd, yd, 3, 1)
+        part = torch.full((rows, 3, c), float("nan"), device=DEV)
+        dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty((2, c), device=DEV)
+        ops.conv3d_fwd(xd, yd, ops.wpack(dtype, 1, w.to(DEV), c, c, 3), None, 1, None, 3, 1, residual=xd,
+                       bn_bwd=(rd, mean, invstd, gamma, beta, None, part),
+                       bn_bwd_fin=(n * sp[0] * sp[1] * sp[2], dg, db, None, coef))
+        torch.cuda.synchronize()
+        gq = from_ndhwc(yd).double()                               # the stored gradient the sums are taken of
+        xhat = (q(r, dtype).double() - mean.cpu().double().view(1, -1, 1, 1, 1)) * invstd.cpu().double().view(1, -1, 1, 1, 1)
+        want_dg, want_db = (gq * xhat).sum((0, 2, 3, 4)), gq.sum((0, 2, 3, 4))
+        assert float((dg.cpu().double() - want_dg).abs().max()) < 2e-4 * float(want_dg.abs().max()) + 1e-3 * float(want_dg.abs().mean())
+        assert float((db.cpu().double() - want_db).abs().max()) < 2e-4 * float(want_db.abs().max()) + 1e-3 * float(want_db.abs().mean())
+    torch.cuda.synchronize()
+    got = from_ndhwc(yd)
+    assert bool(torch.isfinite(got).all())                          # every voxel written (the output started as NaN)
+    assert relerr(got, ref) < BF16_RTOL
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3d_ring_kernel_epilogue(dtype):
     """ring kernel (full-resolution shapes): PReLU + prefetched residual + fused statistics"""
@@ -760,7 +821,7 @@ def test_sw_gather_more_than_16_windows_per_group():
 @pytest.mark.parametrize("K", [4, 16, 3])
 def test_sliding_window_deferred_blend_matches_oracle(K, dtype):
     """segmi_sw_blend: every window kept, one ordered blend pass == the sequential reference
-    (bit-exact in f32), including the argmax and a two-shard partial blend."""
+    (bit-exact in f32), including the argmax and a two-shard partial blend; both kernel variants."""
     from oracle.sliding_ref import ref_sliding_window_inference
     from segmantic_amd.seg.inferers import dense_starts
     img = rnd((1, 1, 20, 27, 33), 93)
@@ -770,7 +831,9 @@ def test_sliding_window_deferred_blend_matches_oracle(K, dtype):
     def predictor(x):   # window predictions rounded to the cache dtype, as the network emits them
         return q(F.conv3d(x, wts, padding=1), dtype)
 
-    for overlap in (0.25, 0.5):
+    # overlap <= 0.5: at most two windows cover a coordinate per dimension -> sw_blend2_kernel (all covering loads
+    # issued up front); 0.75: up to four -> the generic sw_blend_kernel.  Both must reproduce the reference's sums.
+    for overlap in (0.25, 0.5, 0.75):
         ref, cnt_ref, wins = ref_sliding_window_inference(img, roi, 4, predictor, overlap)
         per_dim = dense_starts((20, 27, 33), roi, overlap)
         cache = torch.empty((len(wins),) + roi + (K,), dtype=dtype, device=DEV)
