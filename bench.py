@@ -111,10 +111,10 @@ def csrc_hash() -> str:
 
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (profiles/r03_pmc_traffic.json, written by scripts/make_profiles.py).  PMC counters cannot be
+    (profiles/r04_pmc_traffic.json, written by scripts/make_profiles.py).  PMC counters cannot be
     read from inside the process; the file is used only if it was measured on these very kernel
     sources (``source_hash``), otherwise traffic is null."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     try:
         d = json.load(open(path))
         if d.get("source_hash") == csrc_hash():

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -36,7 +36,7 @@ for wl, name in (("train", "train_b8_128_bf16"), ("infer", "infer_512_bf16")):
         # groups per 512^3 volume (343 windows in groups of 16); the blend runs as 7 z-slab launches per volume
         calls = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(st))}
         dt = sum(v for k, v in calls.items() if "dectop_kernel" in k)
-        steps = str(dt // 22 if dt and dt % 22 == 0 else sum(v for k, v in calls.items() if "sw_blend_kernel" in k))
+        steps = str(dt // 22 if dt and dt % 22 == 0 else sum(v for k, v in calls.items() if "sw_blend" in k) // 7)
     open(os.path.join(OUT, f"{tag}_{name}_kernel_stats.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload infer --steps 2 --warmup 1' if wl == 'infer' else '--workload train --steps 10 --warmup 3'} --no-cpu-baseline\n"
         f"# ({'both streams overlapped' if wl == 'train' else 'one lane (the default)'}; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
@@ -62,10 +62,10 @@ def launches(path, substr, grid):
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (csrc_hash: stamps the measurement to the kernel sources it was taken on)
 
-# training: forward launch of the full-resolution 16 -> 16 conv = first PLAIN ring2 dispatch of 1024
-# workgroups of a step (the second one is the input-gradient launch); batch 8 x 128^3
-fk, kname = launches(f, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 262144)[-2]
-wk, _ = launches(w, "conv_ring2_kernel<unsigned short, 16, 1, 0>", 262144)[-2]
+# training: forward launch of the full-resolution 16 -> 16 conv = the MODE 0 (plain) ring3 dispatch of 1024
+# workgroups of a step (the input-gradient launch of that layer is MODE 4); batch 8 x 128^3
+fk, kname = launches(f, "conv_ring3_kernel<0>", 262144)[-1]
+wk, _ = launches(w, "conv_ring3_kernel<0>", 262144)[-1]
 alg = 8 * 128 ** 3 * 16 * 2 * 2
 # inference: the same layer on a full group of 16 windows (2048 workgroups)
 fi = newest("inf_fetch/*/*counter_collection.csv")
@@ -88,6 +88,9 @@ json.dump({
     "train_top_conv_fwd_hbm_bytes_per_launch": (2 * fk + wk) * 1024, "train_algorithmic_bytes_per_launch": alg,
     "infer_FETCH_SIZE_KB": fki, "infer_WRITE_SIZE_KB": wki,
     "infer_top_conv_fwd_hbm_bytes_per_launch": (2 * fki + wki) * 1024, "infer_algorithmic_bytes_per_launch": alg_i,
-    "note": "reads exceed the input by the (8+2)x(16+2)/(8x16) y/x halo of neighbouring columns that miss L2; writes are exact",
+    "note": "reads exceed the input by the (8+2)x(16+2)/(8x16) y/x halo of neighbouring columns that miss the XCD's L2 "
+            "(round 4: the 1024-workgroup launch no longer uses the XCD-aware column map -- it was 10 % slower with it -- "
+            "so most of the halo is re-fetched past L2; FETCH_SIZE counts Infinity-Cache hits too, MI355X_MICROARCH.md); "
+            "writes are exact",
 }, open(os.path.join(OUT, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print("profiles written:", sorted(os.listdir(OUT)))

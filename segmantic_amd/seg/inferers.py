@@ -130,8 +130,15 @@ def group_factor() -> int:
 # device: taken from torch's caching allocator per call, the freed block gets split by the smaller allocations in
 # between (count map, labels) and every few volumes a call pays a fresh 23 GB hipMalloc -- 0.5 s against 44 ms for
 # the whole volume (bench.py caught it as one timed volume in ten).  SEGMI_SW_KEEP_CACHE=0: allocate per call;
-# ``release_workspaces()`` returns the memory.
+# ``release_workspaces()`` returns the memory -- ``predict()`` calls it when its volumes are done, the fit loop after
+# every validation epoch, so the cache is never pinned beside a training step's activations.
 _CACHE_WS: dict = {}
+
+
+def _cache_key(dev):
+    """one key for get and set: the device index (an index-less ``cuda`` device means the current one)"""
+    dev = torch.device(dev)
+    return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
 def _cache_workspace(dev, shape, dtype):
@@ -139,7 +146,7 @@ def _cache_workspace(dev, shape, dtype):
     dev = torch.device(dev)
     if dev.type != "cuda" or os.environ.get("SEGMI_SW_KEEP_CACHE", "1") == "0":
         return torch.empty(shape, dtype=dtype, device=dev), None
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = _cache_key(dev)
     hit = _CACHE_WS.get(key)
     if hit is not None and tuple(hit[0].shape) == tuple(shape) and hit[0].dtype == dtype:
         return hit[0], hit[1]
@@ -152,7 +159,7 @@ def _cache_workspace(dev, shape, dtype):
 def _cache_release_point(dev, stream):
     """the call is done with the cache once `stream` gets here: the next call (possibly on another stream) waits"""
     dev = torch.device(dev)
-    hit = _CACHE_WS.get(dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else None
+    hit = _CACHE_WS.get(_cache_key(dev)) if dev.type == "cuda" else None
     if hit is not None:
         ev = torch.cuda.Event()
         ev.record(stream)
@@ -390,7 +397,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                 K = pn.shape[4]
                 need = (hi - lo) * nvox_roi * K * pn.element_size()
                 cshape = (hi - lo, roi[0], roi[1], roi[2], K)
-                kept = _CACHE_WS.get(dev.index) if dev.type == "cuda" else None
+                kept = _CACHE_WS.get(_cache_key(dev)) if dev.type == "cuda" else None
                 have = kept is not None and tuple(kept[0].shape) == cshape and kept[0].dtype == pn.dtype
                 deferred = blend != "stream" and max(len(v) for v in per_dim) <= 64 and (
                     blend == "deferred" or have or need <= _cache_budget_bytes(dev))

@@ -510,10 +510,13 @@ def train(
 
 def _train_in_ranks(n_ranks: int, call: dict) -> Optional[Net]:
     """Run ``train(**call)`` as ``n_ranks`` processes (one per entry of ``gpu_ids``) and return the
-    best checkpoint's network (on the CPU; None when no checkpoint was written).  The call travels
-    as a train-config file: the config schema IS the signature (reference ``:400-428``)."""
+    best checkpoint's network THIS launch wrote (on the CPU; None when it wrote none -- checkpoints an
+    earlier run left in ``output_dir`` are not candidates; the single-process ``train()`` returns its
+    live network, whose weights are the last epoch's: load the best file for those too if needed).
+    The call travels as a train-config file: the config schema IS the signature (reference ``:400-428``)."""
     import inspect
     import tempfile
+    import time
 
     from ..utils import config
     from ..utils.cli import cast_from_path
@@ -528,6 +531,7 @@ def _train_in_ranks(n_ranks: int, call: dict) -> Optional[Net]:
     with tempfile.NamedTemporaryFile("w", suffix=".json", prefix="ranks_", dir=str(out), delete=False) as f:
         f.write(config.dumps(plain, is_json=True))
         cfg = f.name
+    started = time.time() - 2.0             # file-system time stamps may be coarser than the clock
     try:
         rc = launch.spawn_ranks(n_ranks, ["-m", "segmantic_amd.commands.monai_unet_cli", "train-config", "-c", cfg])
     finally:
@@ -536,6 +540,8 @@ def _train_in_ranks(n_ranks: int, call: dict) -> Optional[Net]:
         raise RuntimeError(f"segmantic_amd.train: the {n_ranks}-rank launch exited with code {rc}")
     best = None
     for p in out.glob("epoch=*-val_dice=*.ckpt"):
+        if p.stat().st_mtime < started:     # left behind by an earlier run in the same directory
+            continue
         m = re.search(r"val_dice=([0-9.]+?)\.ckpt$", p.name)
         if m and (best is None or float(m.group(1)) > best[0]):
             best = (float(m.group(1)), p)
@@ -698,6 +704,10 @@ def predict(
             print_table(tissue_names[1:], class_dice_sum / np.maximum(class_dice_cnt, 1))
             print("Total Conf. Matrix Metrics:")
             print_table(confusion_metrics, (float(x) for x in conf_matrix.aggregate()))
+    # the sliding-window driver keeps its prediction cache (up to ~23 GB per device) across the volumes of a call;
+    # a process that goes on to train must not find it pinned beside its activations
+    from .inferers import release_workspaces
+    release_workspaces()
 
 
 def _argmax_labels(logits: torch.Tensor) -> torch.Tensor:

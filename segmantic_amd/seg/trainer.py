@@ -389,6 +389,8 @@ def fit(net, output_dir: Path, max_epochs: int, early_stop_patience: int, gpu_id
             broadcast_buffers(net)
         for it in val_cache.items:
             net.validation_step({"image": it["image"][None], "label": it["label"][None]})
+        from .inferers import release_workspaces
+        release_workspaces()      # the validation volumes' prediction cache goes back before the next training epoch
         return net.on_validation_epoch_end(sync=lambda *v: sync_from_rank0(v, device))
 
     run_epochs(net, len(train_cache), step_fn, validate_fn, output_dir, max_epochs,

@@ -149,7 +149,7 @@ def test_bf16_training_forward_vs_oracle_at_benchmark_scale(size, record_propert
     of 64^3 / 128^3, 16 labels, training-mode BatchNorm): relative logit error, argmax agreement and loss deviation
     are RECORDED (junit properties + stdout) and gated at the measured values + margin.  The oracle forward takes a
     few seconds on the test box's host cores; the exact-f32 path is checked on the same input against the north_star
-    gate (1e-3 relative; asserted 3e-4)."""
+    gate (1e-3 relative; asserted 1e-5)."""
     k = 16
     ref, net = build_pair(k, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2))
     img, lab = synthetic_batch(1, size, k, seed=11)
@@ -177,11 +177,13 @@ def test_bf16_training_forward_vs_oracle_at_benchmark_scale(size, record_propert
     for name, v in (("bf16_rel_err", e16), ("bf16_argmax_agreement", agree), ("bf16_loss_rel_dev", dl),
                     ("f32_rel_err", e32), ("f32_argmax_agreement", agree32)):
         record_property(f"{name}_{size}", v)
-    assert e32 < 3e-4, e32
-    assert agree32 > 0.9995, agree32
-    assert e16 < 4e-2, e16
-    assert agree > 0.975, agree
-    assert dl < 1e-2, dl
+    # measured on MI355X (round 4): bf16 8.9e-3 / 99.24 % / 1.3e-6 at 64^3, 7.2e-3 / 99.27 % / 6.9e-7 at 128^3;
+    # f32 9.5e-7 / 100 % and 9.2e-7 / 99.9997 %.  Gates = measured + margin (north_star: 1e-3 on the f32 logits).
+    assert e32 < 1e-5, e32
+    assert agree32 > 0.9999, agree32
+    assert e16 < 2e-2, e16
+    assert agree > 0.985, agree
+    assert dl < 1e-4, dl
 
 
 def test_autograd_bridge_matches_fused_step():
