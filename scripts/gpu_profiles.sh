@@ -1,5 +1,5 @@
 #!/bin/bash
-# profile set (round 2 layout, reused in round 3): the driver-style bench line, kernel stats (overlapped run), per-kernel serial
+# profile set (round 2 layout, reused in rounds 3 and 4): the driver-style bench line, kernel stats (overlapped run), per-kernel serial
 # trace, PMC FETCH/WRITE passes (serial) for training; kernel stats + PMC for inference
 rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
 python bench.py > gpurun_out/prof/bench_all.json 2> gpurun_out/prof/bench_all.err || exit 1
