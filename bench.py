@@ -263,6 +263,7 @@ def run_train(args, precision, rank, world, device, barrier, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         net.training_step(batch)
+    t_host = time.perf_counter() - t0          # the host's share: every launch of the K steps enqueued, nothing waited for
     barrier()
     dt = time.perf_counter() - t0
     eng.timed = None
@@ -271,7 +272,8 @@ def run_train(args, precision, rank, world, device, barrier, steps, warmup):
     roof = roofline_of_top_conv(eng, key, vox, precision, eng._bufs["logits.t"]) if rank == 0 else None
     fpv = conv_flops_per_voxel(eng, True)
     return {"dt": dt, "units": vox * steps, "roofline": roof, "step_conv_flops": vox * fpv, "net": net,
-            "exposed_allreduce_ms": exposed, "grad_bytes": eng.flat_grad.numel() * 4}
+            "exposed_allreduce_ms": exposed, "grad_bytes": eng.flat_grad.numel() * 4,
+            "host_ms_per_step": t_host / steps * 1e3}
 
 
 def run_infer(args, rank, device, barrier, steps, warmup, lanes=None, net=None, vol=None, z_slab=None):
@@ -395,9 +397,10 @@ def run_fit(args, rank, device, barrier, steps, warmup):
         pre.release(pending)
         if i + 1 < steps:
             pending = pre.prepare(order[warmup + i + 1], rng)
+    t_host = time.perf_counter() - t0          # the host's share: every launch of the K steps enqueued, nothing waited for
     barrier()
     dt = time.perf_counter() - t0
-    return {"dt": dt, "units": args.batch * args.size ** 3 * steps, "volume": V}
+    return {"dt": dt, "units": args.batch * args.size ** 3 * steps, "volume": V, "host_ms_per_step": t_host / steps * 1e3}
 
 
 def main():
@@ -449,7 +452,8 @@ def main():
                "config": {"workload": workload, "global_batch": args.batch * world, "patch": args.size,
                           "labels": K, "parallelism": f"dp{world}",
                           "step_conv_TFLOPs": r["step_conv_flops"] / 1e12,
-                          "whole_step_TFLOP_per_s_per_gpu": r["step_conv_flops"] / (dt / args.steps) / 1e12}}
+                          "whole_step_TFLOP_per_s_per_gpu": r["step_conv_flops"] / (dt / args.steps) / 1e12,
+                          "host_enqueue_ms_per_step": round(r["host_ms_per_step"], 3)}}
         if world > 1:
             out["config"]["gradient_exchange"] = {
                 "bytes_per_step": r["grad_bytes"], "buckets": "4 MiB from the end of the arena + tail rule",
@@ -567,7 +571,8 @@ def main():
             fit = {"what": f"training_step fed by the fit loop's on-GPU sampler (4 cached {r['volume']}^3 volumes, 2 volumes x "
                            f"{args.batch // 2} label-class crops + flips per step) instead of a fixed batch",
                    "value": r["units"] * world / dt, "unit": "voxels/s", "ms_per_step": dt / args.steps * 1e3,
-                   "steps": args.steps, "dtype": args.precision}
+                   "steps": args.steps, "dtype": args.precision,
+                   "host_enqueue_ms_per_step": round(r["host_ms_per_step"], 3)}
             if wl == "fit":
                 out = {"metric": f"3D UNet fit (sampler + step) voxels/s on {args.size}^3 {args.precision}",
                        "value": fit["value"], "unit": "voxels/s", "n_gpus": world, "steps": args.steps,

@@ -183,13 +183,13 @@ int segmi_dectop_fwd(int dtype, const segmi_act* in, const segmi_act* out, const
 /* Window views (inference): sample n of `in` is not a slice of a dense batch but the (d, h, w) block that starts
  * offset[n] elements into a larger single-channel volume (`in->data` = the volume, row / plane strides in
  * elements), with ZERO padding at the block's own borders -- the windows of MONAI's sliding_window_inference
- * (monai_unet.py:354-356, 637-639, 665) read in place, instead of being gathered into a batch first.  <= 16
+ * (monai_unet.py:354-356, 637-639, 665) read in place, instead of being gathered into a batch first.  <= 32
  * windows per call; offsets and strides multiples of 4 elements. */
 typedef struct segmi_windows {
   int32_t count;
   int32_t row_stride;
   int64_t plane_stride;
-  int64_t offset[16];
+  int64_t offset[32];
 } segmi_windows;
 int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
                          const segmi_act* out_b);

@@ -33,6 +33,8 @@ def call(role):
         ops.conv3d_fwd(x, y, pkd, None, 1, None, 3, 1, residual=x2)
     elif role == "dgrad_sums":
         ops.conv3d_fwd(x, y, pkd, None, 1, None, 3, 1, bn_bwd=(x2, mean, invstd, gamma, beta, alpha, part))
+    elif role == "fwd_act":   # inference: folded BatchNorm in the pack, PReLU, identity residual
+        ops.conv3d_fwd(x, y, pk, None, 0, b, 3, 1, prelu_alpha=alpha, residual=x)
     elif role == "plain":
         ops.conv3d_fwd(x, y, pkd, None, 1, None, 3, 1)
 
@@ -59,5 +61,5 @@ for role in roles:
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
-    print(f"ring3={os.environ.get('SEGMI_RING3', '1')} xcd={os.environ.get('SEGMI_RING2_XCD', '1')} S={S} dbg={os.environ.get('SEGMI_RING3_DBG', '0'):>2} N={n} {role:10s}: "
+    print(f"ring3={os.environ.get('SEGMI_RING3', '1')} xcd={os.environ.get('SEGMI_RING3_XCD', '-')} zs={os.environ.get('SEGMI_RING_ZS', '1')} S={S} dbg={os.environ.get('SEGMI_RING3_DBG', '0'):>2} N={n} {role:10s}: "
           f"median {ts[5]:7.1f} us  min {ts[0]:7.1f}", flush=True)

@@ -47,7 +47,7 @@ class Windows(C.Structure):
     """``segmi_windows``: the samples of an input are window views into a larger single-channel volume."""
 
     _fields_ = [("count", C.c_int32), ("row_stride", C.c_int32), ("plane_stride", C.c_int64),
-                ("offset", C.c_int64 * 16)]
+                ("offset", C.c_int64 * 32)]
 
 
 class BnFin(C.Structure):

@@ -15,7 +15,7 @@ int conv_mfma_f32(const ConvParams& p, int ksize, int stride, hipStream_t st);
 int conv_mfma_bf16(const ConvParams& p, int ksize, int stride, hipStream_t st);
 int convt_mfma_f32(const ConvTParams& p, hipStream_t st);
 int convt_mfma_bf16(const ConvTParams& p, hipStream_t st);
-int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
+int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st, const BiasFin* bias_fin = nullptr);
 int bn_stats_rows_for(const segmi_act* x);
 int stats_reserve_rows();
 // the separate finalisation launch with a segmi_bn_fin's arguments (generic / direct paths)
@@ -177,12 +177,12 @@ int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a
                   "conv3d_fwd_pair: stats_fin_a needs stats_partials_a and its output pointers");
   if (windows) {
     const int es = dtype_size(dtype);
-    bool ok = in && in->c == 1 && in->ld == 1 && windows->count == in->n && windows->count >= 1 && windows->count <= 16 &&
+    bool ok = in && in->c == 1 && in->ld == 1 && windows->count == in->n && windows->count >= 1 && windows->count <= 32 &&
               windows->row_stride >= in->w && windows->row_stride % 4 == 0 && in->w % 4 == 0 &&
               windows->plane_stride >= (int64_t)windows->row_stride * in->h && windows->plane_stride % 4 == 0 &&
               ((uintptr_t)in->data % (4 * es)) == 0;
     for (int i = 0; ok && i < windows->count; ++i) ok = windows->offset[i] >= 0 && windows->offset[i] % 4 == 0;
-    SEGMI_CHECK_ARG(ok, "conv3d_fwd_pair: bad window views (single channel, <= 16 windows, 4-element aligned "
+    SEGMI_CHECK_ARG(ok, "conv3d_fwd_pair: bad window views (single channel, <= 32 windows, 4-element aligned "
                         "offsets and strides)");
   }
   SEGMI_CHECK_ARG(segmi_conv3d_pair_ok(dtype, in, out_a, out_b),

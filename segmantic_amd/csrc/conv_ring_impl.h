@@ -74,6 +74,8 @@ static inline int conv_ring_zsplit(int dtype, int cin, int ksize, int stride, in
   const int steps = cdiv(Do, 4);
   int zs = 512 / columns;
   if (zs < 1) zs = 1;
+  static const int zs_mul = getenv("SEGMI_RING_ZS") ? atoi(getenv("SEGMI_RING_ZS")) : 1;   // A/B: more, shorter segments
+  if (zs_mul > 1) zs *= zs_mul;
   if (zs > steps / 4) zs = steps / 4;
   if (zs < 1) return 0;
   if (columns * zs < 256) return 0;

@@ -34,7 +34,7 @@ struct SmallConvParams {
   int nwin;
   int wsy;
   int64_t wsz;
-  int64_t woff[16];
+  int64_t woff[32];
   // BatchNorm statistics finalised by the last workgroup of this launch (fin_tail.h)
   int fin_on;
   FinTail ft;

@@ -187,6 +187,7 @@ __device__ __forceinline__ bool fin_tail_run(const float* __restrict__ partials,
 }
 
 // ------------------------------------------------------------------ finalisation functors
+
 // [2][c] column sums (sum, sum of squares) -> per-channel BatchNorm statistics (training mode):
 // mean / invstd for the backward, scale / shift for the apply pass, running statistics update.
 struct BnFin {

@@ -4,6 +4,7 @@
 // softmax lives in registers, reductions are two-stage and deterministic.
 #include "common.h"
 #include "fin_tail.h"
+#include <type_traits>
 
 namespace segmi {
 
@@ -68,10 +69,18 @@ struct DiceParams {
   ChanSumFin cfin;
 };
 
-template <typename T, int KMAX>
+// VECLD: the caller has checked ONCE per workgroup (logits_vec_ok) that every voxel's class row is
+// 16-byte aligned -- a per-voxel alignment test is a divergent branch around every load and keeps the
+// loads of an unrolled trip from being issued together
+template <typename T>
+__device__ __forceinline__ bool logits_vec_ok(const T* base, int k, int ld) {
+  constexpr int VEC = 16 / sizeof(T);
+  return k % VEC == 0 && ld % VEC == 0 && ((uintptr_t)base % 16) == 0;
+}
+template <typename T, int KMAX, bool VECLD>
 __device__ __forceinline__ void load_logits(const T* p, int k, float (&v)[KMAX]) {
   constexpr int VEC = 16 / sizeof(T);
-  if (k % VEC == 0 && ((uintptr_t)p % 16) == 0) {
+  if constexpr (VECLD) {
 #pragma unroll
     for (int j = 0; j < KMAX; j += VEC) {
       if (j < k) {
@@ -126,19 +135,49 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(DiceParams p) {
   float si[KMAX], sp[KMAX], stt[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) si[j] = sp[j] = stt[j] = 0.f;
-  for (int64_t v = v0 + tid; v < v1; v += 256) {
-    float x[KMAX];
-    load_logits<T, KMAX>(lg + v * p.ld, FULL ? KMAX : p.k, x);
-    softmax_inplace<KMAX, sizeof(T) == 2>(FULL ? KMAX : p.k, x);
-    const int lab = (int)lb[v];
+  // U voxels per trip with every load issued before the first softmax (one voxel per trip behind a
+  // per-voxel alignment branch left the 32-byte loads exposed: 3.4 TB/s); the sums keep their voxel
+  // order, so the partials keep their bits
+  auto sweep = [&](auto vec_tag) {
+    constexpr bool VL = decltype(vec_tag)::value;
+    constexpr int U = KMAX <= 16 ? 4 : (KMAX <= 32 ? 2 : 1);
+    int64_t v = v0 + tid;
+    for (; v + 256 * (U - 1) < v1; v += 256 * U) {
+      float x[U][KMAX], lf[U];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      if (FULL || j < p.k) {
-        sp[j] += x[j];
-        if (j == lab) { si[j] += x[j]; stt[j] += 1.f; }
+      for (int u = 0; u < U; ++u) {
+        load_logits<T, KMAX, VL>(lg + (v + 256 * u) * p.ld, FULL ? KMAX : p.k, x[u]);
+        lf[u] = __builtin_nontemporal_load(lb + v + 256 * u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        softmax_inplace<KMAX, sizeof(T) == 2>(FULL ? KMAX : p.k, x[u]);
+        const int lab = (int)lf[u];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          if (FULL || j < p.k) {
+            sp[j] += x[u][j];
+            if (j == lab) { si[j] += x[u][j]; stt[j] += 1.f; }
+          }
+        }
       }
     }
-  }
+    for (; v < v1; v += 256) {
+      float x[KMAX];
+      load_logits<T, KMAX, VL>(lg + v * p.ld, FULL ? KMAX : p.k, x);
+      softmax_inplace<KMAX, sizeof(T) == 2>(FULL ? KMAX : p.k, x);
+      const int lab = (int)lb[v];
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        if (FULL || j < p.k) {
+          sp[j] += x[j];
+          if (j == lab) { si[j] += x[j]; stt[j] += 1.f; }
+        }
+      }
+    }
+  };
+  if (logits_vec_ok<T>(lg, p.k, p.ld)) sweep(std::true_type{});
+  else sweep(std::false_type{});
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
     if (FULL || j < p.k) {
@@ -174,9 +213,12 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
   float gsum[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) gsum[j] = 0.f;
+  const bool vec_in = logits_vec_ok<T>(lg, p.k, p.ld);
+  const bool vec_out = (FULL || p.k % 4 == 0) && p.ldd % 4 == 0 && ((uintptr_t)dl % (4 * sizeof(T))) == 0;
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float x[KMAX];
-    load_logits<T, KMAX>(lg + v * p.ld, FULL ? KMAX : p.k, x);
+    if (vec_in) load_logits<T, KMAX, true>(lg + v * p.ld, FULL ? KMAX : p.k, x);
+    else load_logits<T, KMAX, false>(lg + v * p.ld, FULL ? KMAX : p.k, x);
     softmax_inplace<KMAX, sizeof(T) == 2>(FULL ? KMAX : p.k, x);
     const int lab = (int)lb[v];
     float dot = 0.f;
@@ -189,7 +231,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(DiceParams p) {
       }
     }
     T* o = dl + v * p.ldd;
-    if ((FULL || p.k % 4 == 0) && ((uintptr_t)o % (4 * sizeof(T))) == 0) {
+    if (vec_out) {
 #pragma unroll
       for (int j = 0; j < KMAX; j += 4) {
         if (FULL || j < p.k) {

@@ -68,6 +68,7 @@ struct EwParams {
   int fin_on;
   FinTail ft;
   BnBwdFin bbfin;
+  BiasFin biasfin;     // bn_stats as the bias gradient (segmi_bias_grad): db = channel sums, same launch
   unsigned epoch;      // bn_act_bwd_fused: value the last workgroup publishes in g_fused_flags[ft.ticket]
   unsigned poll_limit; // ... polls before a waiting workgroup gives up (NaN gradients + *tmo += 1)
   unsigned* tmo;       // ... expiry counter in host-mapped memory (segmi_fused_timeouts reads it without a sync)
@@ -117,7 +118,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(EwParams p) {
     const int g = ch / VEC, k = ch % VEC;
     float acc = 0.f;
     for (int v = 0; v < vpp; ++v) acc += red[(v * cg + g) * 2 * VEC + which * VEC + k];
-    p.out_partials[((int64_t)blockIdx.x * 2 + which) * p.c + ch] = acc;
+    fin_store(&p.out_partials[((int64_t)blockIdx.x * 2 + which) * p.c + ch], acc);
+  }
+  {
+    extern __shared__ double stats_tail_lds[];
+    fin_tail_run<BiasFin, 256, offsetof(EwParams, ft), offsetof(EwParams, biasfin)>(p.out_partials, stats_tail_lds);
   }
 }
 
@@ -143,23 +148,34 @@ static inline bool vec4_ok(const segmi_act* a, int dtype) {
   return a->c % 4 == 0 && a->ld % 4 == 0 && ((uintptr_t)a->data % (4 * es)) == 0;
 }
 
-int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st) {
+int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st, const BiasFin* bias_fin) {
   EwParams p{};
   p.x = x->data; p.nvox = act_voxels(x); p.c = x->c; p.ldx = x->ld; p.out_partials = partials;
   p.vpw = stat_vox(p.nvox, p.c);
   const int rows = bn_stats_rows_for(x);
   const bool v4 = vec4_ok(x, dtype) && x->c / 4 <= 256;
+  const bool tail = bias_fin && x->c <= 256;          // the wide-channel fallback keeps the separate fold
+  size_t lds = 0;
+  if (tail) {
+    p.fin_on = 1; p.biasfin = *bias_fin;
+    lds = fin_tail_arm(p, dim3(rows), 256, 2 * x->c, 0);
+  }
   if (v4) {
-    if (dtype == SEGMI_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), rows, 256, 0, st, p);
-    else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 4>), rows, 256, 0, st, p);
+    if (dtype == SEGMI_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), rows, 256, lds, st, p);
+    else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 4>), rows, 256, lds, st, p);
   } else if (x->c <= 256) {
-    if (dtype == SEGMI_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 1>), rows, 256, 0, st, p);
-    else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), rows, 256, 0, st, p);
+    if (dtype == SEGMI_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 1>), rows, 256, lds, st, p);
+    else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), rows, 256, lds, st, p);
   } else {
     if (dtype == SEGMI_F32) hipLaunchKernelGGL(bn_stats_wide_kernel<float>, rows, 256, 0, st, p);
     else hipLaunchKernelGGL(bn_stats_wide_kernel<bf16_t>, rows, 256, 0, st, p);
   }
   SEGMI_LAUNCH_CHECK("bn_stats");
+  if (bias_fin && !tail) {
+    const int width = 2 * x->c;
+    return collapse_fin_launch((const float*)partials, rows, width, fin_scratch((const float*)partials, rows, width), st,
+                               *bias_fin, "bias_grad");
+  }
   return SEGMI_OK;
 }
 
@@ -634,7 +650,7 @@ int segmi_bn_stats_rows(const segmi_act* x) { return x ? bn_stats_rows_for(x) + 
 int segmi_bn_stats(int dtype, const segmi_act* x, float* stats_partials, void* stream) {
   SEGMI_CHECK_ARG(dtype == SEGMI_F32 || dtype == SEGMI_BF16, "bn_stats: bad dtype");
   SEGMI_CHECK_ARG(act_ok(x) && stats_partials, "bn_stats: bad arguments");
-  return bn_stats_launch(dtype, x, stats_partials, (hipStream_t)stream);
+  return bn_stats_launch(dtype, x, stats_partials, (hipStream_t)stream, nullptr);
 }
 
 int segmi_bn_finalize(const float* stats_partials, int rows, int c, double count,

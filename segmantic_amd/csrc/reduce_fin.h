@@ -23,6 +23,15 @@ constexpr int kFinLdsWidth = 4096;  // up to 32 KB of f64 column sums live in LD
                                     // keep them in one more scratch row
 constexpr int kFinScratchRows = kFinBlocks + 1;   // f64 rows of `width` behind a partial table
 
+// column sums [2][c] = {sum dy, sum dy^2} -> db[c]: the bias gradient is the first half
+struct BiasFin {
+  int c;
+  float* db;
+  __device__ void operator()(const double* sums, double*) const {
+    for (int ch = threadIdx.x; ch < c; ch += 256) db[ch] = (float)sums[ch];
+  }
+};
+
 static __device__ unsigned int g_fin_tickets[kFinTickets];
 static std::atomic<unsigned> g_fin_next{0};
 

@@ -24,7 +24,7 @@ namespace segmi {
 
 int wgrad_mfma_f32(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
 int wgrad_mfma_bf16(const WgradParams& p, int ksize, int stride, int ct, int gx, hipStream_t st);
-int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st);
+int bn_stats_launch(int dtype, const segmi_act* x, float* partials, hipStream_t st, const BiasFin* bias_fin = nullptr);
 int bn_stats_rows_for(const segmi_act* x);
 bool conv_small_ok(int cin, int cout, int ksize);
 int conv_small_wgrad_slabs(const segmi_act* dy);
@@ -97,14 +97,48 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partials, int nslab
   }
 }
 
-// collapsed stats [64][2][c] f64 -> db[c] = sum of the "sum" rows (fixed order)
-struct BiasFin {   // sums: [2][c] = {sum dy, sum dy^2}; the bias gradient is the first half
-  int c;
-  float* db;
-  __device__ void operator()(const double* sums, double*) const {
-    for (int ch = threadIdx.x; ch < c; ch += 256) db[ch] = (float)sums[ch];
+// The two passes of the many-slab case in ONE launch (the weight-gradient stream of a training step is a chain of
+// ~20 layers x (weight gradient, reduce, reduce): the second reduce moved 16 rows but cost a dispatch plus the gap in
+// front of it, and the main stream waited ~0.2 ms per step for the end of that chain).  Wave g of a 1024-thread
+// workgroup is slab group g of the two-pass form, a lane is an element: the group sums meet in LDS as the f32
+// values the first pass used to store, and wave 0 adds them in the second pass's order -- the same bits.
+__global__ __launch_bounds__(1024) void slab_reduce_fused_kernel(const float* __restrict__ partials, int nslab,
+                                                                 int64_t n, float* __restrict__ out) {
+  __shared__ float gs[kSlabGroups][64];
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (nslab + kSlabGroups - 1) / kSlabGroups;
+  const int b0 = g * per;
+  const int b1 = b0 + per < nslab ? b0 + per : nslab;
+  for (int64_t e0 = blockIdx.x * 64ll; e0 < n; e0 += (int64_t)gridDim.x * 64) {
+    const int64_t e = e0 + lane;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (e < n) {
+      int b = b0;
+      for (; b + 3 < b1; b += 4) {
+        a0 += (double)partials[(int64_t)b * n + e];
+        a1 += (double)partials[(int64_t)(b + 1) * n + e];
+        a2 += (double)partials[(int64_t)(b + 2) * n + e];
+        a3 += (double)partials[(int64_t)(b + 3) * n + e];
+      }
+      for (; b < b1; ++b) a0 += (double)partials[(int64_t)b * n + e];
+    }
+    gs[g][lane] = (float)((a0 + a1) + (a2 + a3));
+    __syncthreads();
+    if (g == 0 && e < n) {
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+      for (int b = 0; b < kSlabGroups; b += 4) {
+        c0 += (double)gs[b][lane];
+        c1 += (double)gs[b + 1][lane];
+        c2 += (double)gs[b + 2][lane];
+        c3 += (double)gs[b + 3][lane];
+      }
+      out[e] = (float)((c0 + c1) + (c2 + c3));
+    }
+    __syncthreads();
   }
-};
+}
+
 
 static inline bool aligned_rows(const segmi_act* a, int dtype) {
   const int es = dtype_size(dtype);
@@ -151,12 +185,9 @@ int64_t segmi_conv3d_wgrad_workspace(int dtype, const segmi_act* x, const segmi_
 int segmi_bias_grad(int dtype, const segmi_act* dy, float* db, void* workspace, void* stream) {
   SEGMI_CHECK_ARG(act_ok(dy) && db && workspace, "bias_grad: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  int rc = bn_stats_launch(dtype, dy, (float*)workspace, st);
-  if (rc) return rc;
-  const int rows = bn_stats_rows_for(dy), width = 2 * dy->c;
+  // the channel sums are folded by the last workgroup of the statistics launch (fin_tail.h): one launch, not two
   const BiasFin fin{dy->c, db};
-  return collapse_fin_launch((const float*)workspace, rows, width,
-                             fin_scratch((const float*)workspace, rows, width), st, fin, "bias_grad");
+  return bn_stats_launch(dtype, dy, (float*)workspace, st, &fin);
 }
 
 int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float* dw,
@@ -185,7 +216,7 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
     p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
     p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
     if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
-    const int ct = wgrad_ct(dtype, x->c, dy->c);
+    const int ct = wgrad_ct_for(dtype, x, dy, ksize, stride, cus);
     const bool ws = wgrad_ws_gx(dtype, x, dy, ksize, stride, cus) > 0;
     const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, slabs, st)
                                       : wgrad_mfma_bf16(p, ksize, stride, ws ? -ct : ct, slabs, st);
@@ -205,7 +236,11 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
   }
   const int rb = (int)(cdiv64(nout, 256) > 2048 ? 2048 : cdiv64(nout, 256));
   float* gsum = (float*)((char*)workspace + align256((int64_t)slabs * nout * 4));
-  if (slabs > 2 * kSlabGroups) {
+  static const bool two_launches = getenv("SEGMI_SLAB_REDUCE2") && atoi(getenv("SEGMI_SLAB_REDUCE2")) == 1;   // A/B
+  if (slabs > 2 * kSlabGroups && !two_launches) {
+    const int fb = (int)(cdiv64(nout, 64) > 4096 ? 4096 : cdiv64(nout, 64));
+    hipLaunchKernelGGL(slab_reduce_fused_kernel, dim3(fb), 1024, 0, st, (const float*)partials, slabs, nout, dw);
+  } else if (slabs > 2 * kSlabGroups) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb, kSlabGroups), 256, 0, st, (const float*)partials,
                        slabs, nout, gsum);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb, 1), 256, 0, st, (const float*)gsum, kSlabGroups,

@@ -372,10 +372,9 @@ static inline bool wgrad_ws_cfg_ok(int stride, int ct) {
 // EVERY CU the dependent chain of the main stream gets no CU until they retire; sized for half the chip the two
 // streams really run side by side (5.55 -> 5.28 ms per training step, round 3).
 int wgrad_cus(int cus);
-static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus) {
+static inline int wgrad_ws_gx_ct(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus, int ct) {
   static const bool enabled = !(getenv("SEGMI_WGRAD_WS") && atoi(getenv("SEGMI_WGRAD_WS")) == 0);
   if (!enabled || dtype != SEGMI_BF16 || ksize != 3) return 0;
-  const int ct = wgrad_ct(dtype, x->c, dy->c);
   if (!wgrad_ws_cfg_ok(stride, ct)) return 0;
   const int cto = ct / 10, cti = ct % 10;
   const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
@@ -391,10 +390,31 @@ static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy
   if (act_voxels(x) * x->ld * 2 >= 0xfff00000ll || act_voxels(dy) * dy->ld * 2 >= 0xfff00000ll) return 0;
   return nt >= 4 * (int64_t)gx ? gx : 0;
 }
+// Channel tile of THIS layer.  Layers with >= 32 input and output channels took the 2 x 2 tile of wgrad_mfma_kernel
+// (220 VGPRs, one workgroup per CU) until round 4; with the 2 x 1 tile (32 output x 16 input channels per workgroup:
+// the wave-specialised kernel where the layer has the tiles for it, wgrad_mfma_kernel's 2 x 1 form elsewhere) the
+// training step went 4.98 -> 4.75 ms and the 160^3 / 32-label step at batch 4 11.1 -> 9.9 ms, alternating runs
+// (the operand read twice costs less than the 2 x 2 tile's occupancy).  SEGMI_WGRAD_CT22 (A/B): 22 = the 2 x 2 tile
+// as before (4.98), 2122 = 2 x 1 only where the wave-specialised kernel then takes the layer (4.79), 11 / 1122
+// likewise with 1 x 1 (4.82 / 4.82).
+static inline int wgrad_ct_for(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus) {
+  const int ct = wgrad_ct(dtype, x->c, dy->c);
+  if (ct != 22) return ct;
+  static const int mode = getenv("SEGMI_WGRAD_CT22") ? atoi(getenv("SEGMI_WGRAD_CT22")) : 21;
+  if (mode == 21 || mode == 11) return mode;
+  if (mode == 2122 || mode == 1122) {
+    const int alt = mode / 100;
+    return wgrad_ws_gx_ct(dtype, x, dy, ksize, stride, cus, alt) > 0 ? alt : 22;
+  }
+  return ct;
+}
+static inline int wgrad_ws_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus) {
+  return wgrad_ws_gx_ct(dtype, x, dy, ksize, stride, cus, wgrad_ct_for(dtype, x, dy, ksize, stride, cus));
+}
 static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus_arg) {
   const int ws = wgrad_ws_gx(dtype, x, dy, ksize, stride, cus_arg);
   if (ws > 0) return ws;
-  const int ct = wgrad_ct(dtype, x->c, dy->c);
+  const int ct = wgrad_ct_for(dtype, x, dy, ksize, stride, cus_arg);
   const int cto = ct / 10, cti = ct % 10;
   const int chunks = (x->c / (16 * cti)) * (dy->c / (16 * cto));
   // workgroups wanted = a multiple of the 256 CUs; one per CU once the kernel holds > 1 channel

@@ -38,7 +38,7 @@ def _require_device(t: torch.Tensor) -> None:
 
 class WindowBatch:
     """A batch of sliding windows read IN PLACE: ``volume`` [D, H, W] (contiguous, single channel, compute
-    dtype) and the (z, y, x) origins of <= 16 windows of extent ``roi`` that lie inside it.  Quacks like the
+    dtype) and the (z, y, x) origins of <= 32 windows of extent ``roi`` that lie inside it.  Quacks like the
     NDHWC tensor [n, *roi, 1] it stands for (``shape``, ``dtype``, ``device``); only the first-layer pair
     kernel (``conv3d_fwd_pair``) reads it (``segmi_windows``)."""
 
@@ -48,8 +48,8 @@ class WindowBatch:
         self.volume, self.roi = volume, tuple(int(r) for r in roi)
         self.starts = [tuple(int(v) for v in s) for s in starts]
         D, H, W = volume.shape
-        if not 1 <= len(self.starts) <= SW_MAX_WINDOWS:
-            raise ValueError("WindowBatch: 1 .. 16 windows")
+        if not 1 <= len(self.starts) <= SW_MAX_VIEWS:
+            raise ValueError(f"WindowBatch: 1 .. {SW_MAX_VIEWS} windows")
         for s in self.starts:
             if any(a < 0 or a + r > n for a, r, n in zip(s, self.roi, (D, H, W))):
                 raise ValueError(f"WindowBatch: window {s} + {self.roi} leaves the volume {tuple(volume.shape)}")
@@ -548,6 +548,7 @@ def _starts(starts: Sequence[Sequence[int]], width: int):
     return arr, arr.ctypes.data_as(C.c_void_p)
 
 
+SW_MAX_VIEWS = 32       # window views per first-layer call (segmi_windows.offset in include/segmi.h)
 SW_MAX_WINDOWS = 16     # windows per segmi_sw_gather / segmi_sw_scatter_add call (kMaxWin in sliding.hip)
 
 

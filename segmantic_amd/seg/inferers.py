@@ -287,7 +287,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
     # the volume is cast to the compute dtype once and the first-layer kernel takes the windows as views
     # (ops.WindowBatch / segmi_windows) -- no gather pass, no window batch in HBM.  SEGMI_SW_VIEWS=0: gather.
     views_ok = (into is not None and Cin == 1 and not any(pad_lo) and all(o >= r for o, r in zip(orig, roi))
-                and os.environ.get("SEGMI_SW_VIEWS", "1") != "0" and sw_batch_size <= ops.SW_MAX_WINDOWS
+                and os.environ.get("SEGMI_SW_VIEWS", "1") != "0" and sw_batch_size <= ops.SW_MAX_VIEWS
                 and ops.WindowBatch.eligible(orig, wins_u[lo:hi], roi)
                 and getattr(owner, "window_views_ok", lambda d: False)(window_dtype))
     for b in range(B):

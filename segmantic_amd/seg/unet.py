@@ -1225,8 +1225,11 @@ class UNetEngine:
     # top transposed convolution.  Same arithmetic in the same order per parameter: bit-identical weights
     # (tests/test_e2e_gpu.py).  SEGMI_CARRY_TOP_WGRAD=0: everything inside the step, as before.
     carry_top_wgrad = os.environ.get("SEGMI_CARRY_TOP_WGRAD", "1") != "0"
-    # how many of the upper levels' up paths are carried (1 = the full-resolution decoder only)
-    carry_levels = int(os.environ.get("SEGMI_CARRY_LEVELS", "1"))
+    # how many of the upper levels' up paths are carried (1 = the full-resolution decoder only).  Round 4: 2 -- the
+    # weight-gradient stream was still ~0.2 ms behind when the main chain reached the optimiser (the 64^3 decoder's
+    # weight gradients sat in front of the first encoder layers', which the next forward needs first); with the
+    # 64^3 up path carried too the step went 5.02 -> 4.91 ms (alternating runs); 3: 4.99, 4: 5.25.
+    carry_levels = int(os.environ.get("SEGMI_CARRY_LEVELS", "2"))
     _carry_open = False
     _carried: list = []
     _tail_ev = None
