@@ -158,8 +158,33 @@ static inline int wg_direct_blocks(const segmi_act* dy) {
   return (int)(b > 1024 ? 1024 : b);
 }
 static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+// The wave-specialised kernel addresses each operand through ONE buffer descriptor (32-bit offsets, < 4 GiB).  A
+// layer that misses it only for that (160^3 x 32 channels x batch 8 inside a 64-channel skip buffer = 4.2 GB) is
+// cut along the batch into 2 / 4 / 8 parts that fit: one launch per part, each with its own slabs, one reduce.
+static inline segmi_act batch_part(const segmi_act* a, int parts, int i, int dtype) {
+  segmi_act s = *a;
+  s.n = a->n / parts;
+  s.data = (char*)a->data + (int64_t)i * s.n * a->d * a->h * a->w * a->ld * dtype_size(dtype);
+  return s;
+}
+static inline int wg_batch_parts(int dtype, const segmi_act* x, const segmi_act* dy, int ksize, int stride, int cus) {
+  if (!wg_mfma_ok(dtype, x, dy, ksize) || wgrad_ws_gx(dtype, x, dy, ksize, stride, cus) > 0) return 1;
+  const int64_t lim = 0xfff00000ll;
+  if (act_voxels(x) * x->ld * 2 < lim && act_voxels(dy) * dy->ld * 2 < lim) return 1;   // not the size that keeps it out
+  for (int parts = 2; parts <= 8 && parts <= x->n; parts *= 2) {
+    if (x->n % parts) break;
+    const segmi_act xs = batch_part(x, parts, 0, dtype), ys = batch_part(dy, parts, 0, dtype);
+    if (wgrad_ws_gx(dtype, &xs, &ys, ksize, stride, cus) > 0) return parts;
+  }
+  return 1;
+}
 static inline int wg_slabs(int dtype, const segmi_act* x, const segmi_act* dy, int ksize,
                            int stride, int cus) {
+  const int parts = wg_batch_parts(dtype, x, dy, ksize, stride, cus);
+  if (parts > 1) {
+    const segmi_act xs = batch_part(x, parts, 0, dtype), ys = batch_part(dy, parts, 0, dtype);
+    return parts * wgrad_gx(dtype, &xs, &ys, ksize, stride, cus);
+  }
   if (wg_mfma_ok(dtype, x, dy, ksize)) return wgrad_gx(dtype, x, dy, ksize, stride, cus);
   if (wg_small_ok(dtype, x, dy, ksize)) return conv_small_wgrad_slabs(dy);
   return wg_direct_blocks(dy);
@@ -211,16 +236,21 @@ int segmi_conv3d_wgrad(int dtype, const segmi_act* x, const segmi_act* dy, float
   float* partials = (float*)workspace;
   const int slabs = wg_slabs(dtype, x, dy, ksize, stride, cus);
   if (wg_mfma_ok(dtype, x, dy, ksize)) {
-    WgradParams p{};
-    p.x = x->data; p.dy = dy->data; p.partials = partials;
-    p.N = x->n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
-    p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
-    if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
-    const int ct = wgrad_ct_for(dtype, x, dy, ksize, stride, cus);
-    const bool ws = wgrad_ws_gx(dtype, x, dy, ksize, stride, cus) > 0;
-    const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, slabs, st)
-                                      : wgrad_mfma_bf16(p, ksize, stride, ws ? -ct : ct, slabs, st);
-    if (rc) return rc;
+    const int parts = wg_batch_parts(dtype, x, dy, ksize, stride, cus);
+    for (int part = 0; part < parts; ++part) {
+      const segmi_act xs = batch_part(x, parts, part, dtype), ys = batch_part(dy, parts, part, dtype);
+      const int gx = slabs / parts;
+      WgradParams p{};
+      p.x = xs.data; p.dy = ys.data; p.partials = partials + (int64_t)part * gx * nout;
+      p.N = xs.n; p.Dx = x->d; p.Hx = x->h; p.Wx = x->w; p.Dy = dy->d; p.Hy = dy->h; p.Wy = dy->w;
+      p.Cin = x->c; p.Cout = dy->c; p.ldx = x->ld; p.ldy = dy->ld;
+      if (in_tf) { p.in_scale = in_tf->scale; p.in_shift = in_tf->shift; p.in_alpha = in_tf->prelu_alpha; }
+      const int ct = wgrad_ct_for(dtype, &xs, &ys, ksize, stride, cus);
+      const bool ws = wgrad_ws_gx(dtype, &xs, &ys, ksize, stride, cus) > 0;
+      const int rc = dtype == SEGMI_F32 ? wgrad_mfma_f32(p, ksize, stride, ct, gx, st)
+                                        : wgrad_mfma_bf16(p, ksize, stride, ws ? -ct : ct, gx, st);
+      if (rc) return rc;
+    }
   } else if (wg_small_ok(dtype, x, dy, ksize)) {
     const int rc = conv_small_wgrad(dtype, x, dy, partials, stride, st);
     if (rc) return rc;

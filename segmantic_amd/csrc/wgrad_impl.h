@@ -388,7 +388,8 @@ static inline int wgrad_ws_gx_ct(int dtype, const segmi_act* x, const segmi_act*
   const int64_t nt = (int64_t)dy->n * cdiv(dy->d, td) * cdiv(dy->h, th) * cdiv(dy->w, tw);
   // raw buffer loads: 32-bit offsets / num_records over each tensor
   if (act_voxels(x) * x->ld * 2 >= 0xfff00000ll || act_voxels(dy) * dy->ld * 2 >= 0xfff00000ll) return 0;
-  return nt >= 4 * (int64_t)gx ? gx : 0;
+  static const int min_tiles = getenv("SEGMI_WGRAD_WS_MINT") ? atoi(getenv("SEGMI_WGRAD_WS_MINT")) : 4;   // A/B
+  return nt >= min_tiles * (int64_t)gx ? gx : 0;
 }
 // Channel tile of THIS layer.  Layers with >= 32 input and output channels took the 2 x 2 tile of wgrad_mfma_kernel
 // (220 VGPRs, one workgroup per CU) until round 4; with the 2 x 1 tile (32 output x 16 input channels per workgroup:
@@ -422,7 +423,8 @@ static inline int wgrad_gx(int dtype, const segmi_act* x, const segmi_act* dy, i
   // 704/508/540/608 us at 256/512/1024/2048 workgroups, 2x2 blocks 125/198/348 us at 256/512/1024.
   static const int mfma_env = getenv("SEGMI_WGRAD_CUS_MFMA") ? atoi(getenv("SEGMI_WGRAD_CUS_MFMA")) / 8 * 8 : 0;   // experiments
   const int cus = mfma_env >= 8 ? mfma_env : wgrad_cus(cus_arg);
-  const int target = cto * cti == 1 ? 2 * cus : cus;
+  static const int mul21 = getenv("SEGMI_WGRAD_MUL21") ? atoi(getenv("SEGMI_WGRAD_MUL21")) : 1;             // A/B
+  const int target = cto * cti == 1 ? 2 * cus : (cto * cti == 2 ? mul21 * cus : cus);
   int gx = target / chunks;
   if (gx < 1) gx = 1;
   const int nt = wgrad_tiles(dy, stride, cto * cti == 1);

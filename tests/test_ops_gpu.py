@@ -1290,6 +1290,9 @@ WS_WGRAD_CASES = [
     (16, 16, 3, 1, (40, 64, 8), 8),        # narrow volumes: the 8-wide tile, tap-split consumers
     (32, 16, 3, 1, (18, 64, 128), 2),      # 32 input channels: X staged in two 16-channel chunks (ci0 = 0, 16)
     (32, 16, 3, 2, (64, 64, 128), 2),      # the same with stride 2
+    (32, 32, 3, 1, (18, 64, 128), 4),      # >= 32 channels on both sides: the 2 x 1 channel tile (round 4), grid.y = 2
+    (64, 32, 3, 1, (18, 64, 128), 2),      # four input-channel chunks
+    (32, 64, 3, 2, (64, 64, 128), 2),      # stride 2 with two output-channel chunks of 32
 ]
 
 
@@ -1328,6 +1331,37 @@ def test_wave_specialised_wgrad_matches_torch(case):
     ops.conv3d_wgrad(xd, dyd, dw_tf, None, k, s, ws, in_tf=(scale, shift, alpha))
     torch.cuda.synchronize()
     assert torch.equal(dw_ref, dw_tf)
+
+
+def test_wgrad_of_an_operand_past_the_4GiB_descriptor_is_cut_along_the_batch():
+    """A channel slice of a wide buffer at BASELINE config 4's extent -- 8 x 160^3 voxels x 96 channels x 2 B =
+    6.3 GB -- is more than one buffer descriptor of the wave-specialised kernel covers (32-bit offsets, < 4 GiB).
+    The call is cut into batch parts that fit (one launch each, one reduce over all slabs) instead of falling back
+    to the tile-at-a-time kernel.  Checked through linearity in the batch: the gradient of the whole batch is the sum
+    of the gradients of its halves (each of which the kernel takes directly), in f32 round-off."""
+    n, S, c = 8, 160, 32
+    g = torch.Generator(device=DEV).manual_seed(77)
+    wide = torch.empty((n, S, S, S, 3 * c), dtype=torch.bfloat16, device=DEV)
+    for i in range(n):
+        wide[i] = torch.randn((S, S, S, 3 * c), device=DEV, generator=g).bfloat16()
+    dy = torch.empty((n, S, S, S, c), dtype=torch.bfloat16, device=DEV)
+    for i in range(n):
+        dy[i] = torch.randn((S, S, S, c), device=DEV, generator=g).bfloat16()
+    x = wide[..., c:2 * c]
+    assert x.numel() // c * 3 * c * 2 > 0xfff00000
+    dw = [torch.full((c, c, 3, 3, 3), float("nan"), device=DEV) for _ in range(3)]
+    ws = torch.empty(ops.conv3d_wgrad_workspace(x, dy, 3, 1), dtype=torch.uint8, device=DEV)
+    ops.conv3d_wgrad(x, dy, dw[0], None, 3, 1, ws)
+    h = n // 2
+    ops.conv3d_wgrad(x[:h], dy[:h], dw[1], None, 3, 1, ws)
+    ops.conv3d_wgrad(x[h:], dy[h:], dw[2], None, 3, 1, ws)
+    torch.cuda.synchronize()
+    want = dw[1].double() + dw[2].double()
+    assert torch.isfinite(dw[0]).all()
+    assert float((dw[0].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # and it is the wave-specialised kernel's partition: twice the slabs of one half
+    half = ops.conv3d_wgrad_workspace(x[:h], dy[:h], 3, 1)
+    assert ops.conv3d_wgrad_workspace(x, dy, 3, 1) > half
 
 
 # ------------------------------------------------------------------ finalisation inside the producing launch
