@@ -267,8 +267,8 @@ int segmi_conv3d_in_affine_ok(int dtype, const segmi_act* in, const segmi_act* o
 int segmi_conv3d_bn_bwd_sums_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                                 int stride) {
   if (!act_ok(in) || !act_ok(out) || dtype != SEGMI_BF16) return 0;
-  // the ring kernel's 16-channel single-tile variant (conv_ring2_kernel<bf16, 16, 1, MODE 4>)
-  return in->c == 16 && out->c == 16 && ksize == 3 && stride == 1 &&
+  // the ring kernels' MODE 4: 16 -> 16 (conv_ring3 / conv_ring2<bf16, 16, 1>) and 32 -> 32 (conv_ring2<bf16, 32, 2>)
+  return ((in->c == 16 && out->c == 16) || (in->c == 32 && out->c == 32)) && ksize == 3 && stride == 1 &&
                  conv_ring_ok(dtype, in->c, ksize, stride, out) ? 1 : 0;
 }
 

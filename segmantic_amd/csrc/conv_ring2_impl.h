@@ -605,7 +605,10 @@ static int launch_conv_ring2_k(ConvParams p, hipStream_t st) {
 
 template <typename T, int CK, int NT>
 static int launch_conv_ring2_cfg(const ConvParams& p, hipStream_t st) {
-  if constexpr (CK == 16 && NT == 1) {
+  if constexpr (NT == 1) {
+    // MODE 4 (BatchNorm-backward sums in the input-gradient launch): 16 -> 16, and 32 -> 32 (BASELINE config 4's
+    // full-resolution layers, round 4) as two 16-channel output tiles on grid.y -- with both tiles in one workgroup
+    // (NT = 2: 216 weight registers + the sums) the variant spills 96 registers and the step got slower
     if (p.bpart && !p.alpha && !p.stats) return launch_conv_ring2_k<T, CK, NT, 4>(p, st);
   }
   switch ((p.alpha ? 1 : 0) | (p.stats ? 2 : 0)) {
@@ -621,7 +624,8 @@ static int launch_conv_ring2(const ConvParams& p, hipStream_t st) {
   const int ck = pick_ck(SEGMI_BF16, p.Cin);
   const int nt = p.Cout / 16;
   if (ck == 32) {
-    if (nt % 2 == 0) return launch_conv_ring2_cfg<bf16_t, 32, 2>(p, st);
+    const bool sums = p.bpart && !p.alpha && !p.stats;
+    if (nt % 2 == 0 && !sums) return launch_conv_ring2_cfg<bf16_t, 32, 2>(p, st);
     return launch_conv_ring2_cfg<bf16_t, 32, 1>(p, st);
   }
   return launch_conv_ring2_cfg<bf16_t, 16, 1>(p, st);

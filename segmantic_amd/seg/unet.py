@@ -698,9 +698,16 @@ class UNetEngine:
     def _bsum_ok(self, conv: _Conv, dy, dx, bn: Optional["_BN"]) -> bool:
         """the BatchNorm-backward reduction of `bn` (whose output gradient is dx = dgrad(conv, dy)) can
         run in that input-gradient launch's epilogue (segmi_bn_bwd_sums)"""
+        # 32 -> 32 layers (BASELINE config 4): the kernel takes the sums (tested), this engine does not ask for them --
+        # the variant that fits its registers computes the 32 outputs as two 16-channel tiles on grid.y and the
+        # 160^3 / batch 4 step went 9.75 -> 10.2 ms with it (both tiles in one workgroup: 96 spilled registers,
+        # 10.9 ms).  SEGMI_BSUM32=1 asks for them anyway (A/B).
         return (bn is not None and self.fuse_bn_bwd and self.dtype == torch.bfloat16 and self.dropout_p <= 0.0
                 and not conv.transposed and conv.stride == 1 and conv.k == 3 and conv.mfma
+                and (conv.cout == 16 or self._bsum32)
                 and ops.conv3d_bn_bwd_sums_ok(dy, dx, 3, 1))
+
+    _bsum32 = os.environ.get("SEGMI_BSUM32", "0") == "1"
 
     def _dgrad(self, conv: _Conv, dy, dx, residual=None, bsum=None):
         """dx = dgrad(conv, dy) (+ residual).  ``bsum`` = (bn, x_raw): also the partial rows of that

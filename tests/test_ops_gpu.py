@@ -1175,13 +1175,14 @@ def test_bn_bwd_sums_stay_accurate_when_the_mean_dwarfs_the_spread():
     assert float((db.cpu().double() - want_db).abs().max()) < 2e-4 * float(want_db.abs().max()) + 1e-3 * float(want_db.abs().mean())
 
 
+@pytest.mark.parametrize("c", [16, 32])
 @pytest.mark.parametrize("shape,residual", [((2, 32, 64, 128), "in"), ((2, 33, 60, 120), "other"), ((4, 16, 64, 128), None)])
-def test_bn_bwd_sums_in_the_input_gradient_epilogue_match_the_separate_pass(shape, residual):
+def test_bn_bwd_sums_in_the_input_gradient_epilogue_match_the_separate_pass(shape, residual, c):
     """segmi_bn_bwd_sums: the ring kernel's input-gradient launch also writes the partial rows of the
     BatchNorm-backward reduction over (its own stored output, x_raw).  Same dx bits; dgamma / dbeta /
-    dalpha / coef equal to the separate two-tensor pass up to f32 summation order."""
+    dalpha / coef equal to the separate two-tensor pass up to f32 summation order.  c = 32: the 32 -> 32
+    full-resolution layers of BASELINE config 4 (conv_ring2<bf16, 32, 2>, round 4)."""
     n, d, h, w = shape
-    c = 16
     dy = rnd((n, c, d, h, w), 401, 0.5)
     xr = rnd((n, c, d, h, w), 402, 2.0) + 0.3
     wt = rnd((c, c, 3, 3, 3), 403, 0.08)
