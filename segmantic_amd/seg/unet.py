@@ -1314,7 +1314,7 @@ class UNetEngine:
 
     # residual-branch overlap on a second side stream: measured neutral on MI355X (the branch
     # convs are short and the join sits on the critical path), so it is off by default
-    overlap_branches = False
+    overlap_branches = os.environ.get("SEGMI_OVERLAP_BRANCHES", "0") == "1"
     # BatchNorm-apply + PReLU folded into the consumer conv's staging where the kernels allow it
     # (segmi_in_affine); SEGMI_FUSE_BN=0 keeps the separate pass for A/B measurements
     fuse_bn_apply = os.environ.get("SEGMI_FUSE_BN", "1") != "0"
