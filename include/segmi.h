@@ -73,6 +73,10 @@ typedef struct segmi_wpack_desc {
   const float* scale;  /* device f32[cout_k] or NULL                                 */
   void* packed;        /* device destination, segmi_wpack_bytes(...) bytes            */
   int32_t kind, cin_k, cout_k, ksize;
+  /* kind 0 only: output channels >= cout_split come from a second source [cout_k - cout_split][cin_k][taps]
+   * (the pair pack of segmi_conv3d_fwd_split_act out of two separate parameter tensors); NULL = one source */
+  const float* w_src2;
+  int32_t cout_split, reserved;
 } segmi_wpack_desc;
 int segmi_wpack_batch(int dtype, const segmi_wpack_desc* descs_host, int ndesc,
                       segmi_wpack_desc* descs_dev, int upload, void* stream);
@@ -198,12 +202,19 @@ int segmi_conv3d_pair_ok(int dtype, const segmi_act* in, const segmi_act* out_a,
  * (segmi_wpack of the concatenated [2c][cin][27] weight, per-channel scale = folded BatchNorm for the
  * first c outputs, 1 for the rest) writes 2c channels, PReLU only on the first `act_channels`:
  *   out[..., :act_channels] = prelu(conv_a(in) + bias[:c]) ; out[..., act_channels:] = conv_b(in) + bias[c:]
- * Consumers read the two halves as channel-slice views (ld = 2c).  Same bits as the two calls. */
+ * Consumers read the two halves as channel-slice views (ld = 2c).  Same bits as the two calls.
+ * Training (round 4; replaces the two torch convolutions of a ResidualUnit's first subunit and residual path,
+ * monai_unet.py:341 through monai.networks.blocks.ResidualUnit): prelu_alpha = NULL, `bias_b` = the second
+ * convolution's bias (nullable: then bias holds all 2c values), `stats_partials` / `stats_fin` = BatchNorm statistics
+ * rows [segmi_conv3d_stats_rows][2][act_channels] of the FIRST act_channels outputs and their finalisation in the
+ * same launch; the pack comes from a segmi_wpack_desc with two sources (w_src2 / cout_split). */
 int segmi_conv3d_split_act_ok(int dtype, const segmi_act* in, const segmi_act* out, int ksize,
                               int stride);
 int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* out,
                                const void* packed, const float* bias, const float* prelu_alpha,
-                               int act_channels, int ksize, int stride, void* stream);
+                               int act_channels, int ksize, int stride,
+                               const float* bias_b /* nullable */, float* stats_partials /* nullable */,
+                               const segmi_bn_fin* stats_fin /* nullable; needs stats_partials */, void* stream);
 int segmi_conv3d_fwd_pair(int dtype, const segmi_act* in, const segmi_act* out_a, const float* w_a,
                           const float* bias_a, const float* prelu_alpha_a, float* stats_partials_a,
                           const segmi_act* out_b, const float* w_b, const float* bias_b, int stride,

@@ -34,7 +34,8 @@ class WpackDesc(C.Structure):
 
     _fields_ = [("w_src", C.c_void_p), ("scale", C.c_void_p), ("packed", C.c_void_p),
                 ("kind", C.c_int32), ("cin_k", C.c_int32), ("cout_k", C.c_int32),
-                ("ksize", C.c_int32)]
+                ("ksize", C.c_int32), ("w_src2", C.c_void_p), ("cout_split", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class InAffine(C.Structure):
@@ -94,7 +95,7 @@ SIGNATURES = {
     "segmi_conv3d_in_affine_ok": (_i, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_fwd_kernel_name": (C.c_char_p, [_i, _AP, _AP, _i, _i]),
     "segmi_conv3d_split_act_ok": (_i, [_i, _AP, _AP, _i, _i]),
-    "segmi_conv3d_fwd_split_act": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _i, _i, _P]),
+    "segmi_conv3d_fwd_split_act": (_i, [_i, _AP, _AP, _P, _P, _P, _i, _i, _i, _P, _P, C.POINTER(BnFin), _P]),
     "segmi_conv3d_fwd": (_i, [_i, _AP, _AP, _P, _P, _i, _P, _P, _AP, _P, _i, _i, C.POINTER(InAffine),
                               C.POINTER(BnBwdSums), C.POINTER(BnFin), _P]),
     "segmi_conv3d_bn_bwd_sums_ok": (_i, [_i, _AP, _AP, _i, _i]),

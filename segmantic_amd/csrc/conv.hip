@@ -207,7 +207,8 @@ int segmi_conv3d_split_act_ok(int dtype, const segmi_act* in, const segmi_act* o
 
 int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* out, const void* packed,
                                const float* bias, const float* prelu_alpha, int act_channels, int ksize,
-                               int stride, void* stream) {
+                               int stride, const float* bias_b, float* stats_partials,
+                               const segmi_bn_fin* stats_fin, void* stream) {
   SEGMI_CHECK_ARG(segmi_conv3d_split_act_ok(dtype, in, out, ksize, stride),
                   "conv3d_fwd_split_act: layer not eligible (ask segmi_conv3d_split_act_ok)");
   SEGMI_CHECK_ARG(packed && act_channels > 0 && act_channels % 16 == 0 && act_channels <= out->c,
@@ -227,6 +228,15 @@ int segmi_conv3d_fwd_split_act(int dtype, const segmi_act* in, const segmi_act* 
   p.nchunks = in->c / pick_ck(dtype, in->c);
   p.ntiles_total = out->c / 16;
   p.act_tiles = act_channels / 16;
+  p.bias2 = bias_b;
+  if (stats_partials) {
+    // training: statistics (and their finalisation) of the first act_channels outputs only
+    p.stats = stats_partials;
+    p.stats_tiles = act_channels / 16;
+    if (stats_fin) { p.fin_on = 1; p.bfin = bn_fin_from(stats_fin, act_channels); }
+  } else {
+    SEGMI_CHECK_ARG(!stats_fin, "conv3d_fwd_split_act: stats_fin needs stats_partials");
+  }
   hipStream_t st = (hipStream_t)stream;
   return dtype == SEGMI_F32 ? conv_mfma_f32(p, ksize, stride, st) : conv_mfma_bf16(p, ksize, stride, st);
 }

@@ -32,8 +32,13 @@ struct ConvParams {
   const float* in_alpha;
   // PReLU applies to output-channel tiles < act_tiles only (0 = all): segmi_conv3d_fwd_split_act runs
   // two convolutions of one input as ONE launch with 2c outputs of which the first c are activated.
-  // Honoured by the tile kernel (conv_fwd_mfma_kernel) only.
+  // Honoured by the tile kernel (conv_fwd_mfma_kernel) only.  In TRAINING the same pairing carries the
+  // BatchNorm statistics of the first convolution only: stats_tiles > 0 = statistics rows of 16 * stats_tiles
+  // channels, written (and finalised) by the workgroups of those tiles; bias2 = the second convolution's bias
+  // (tiles >= act_tiles read bias2[(tile - act_tiles) * 16 ...]: the two biases are separate arena slots).
   int act_tiles;
+  int stats_tiles;
+  const float* bias2;
   // optional BatchNorm-backward sums in the epilogue (segmi_bn_bwd_sums; ring kernel, MODE 4): the
   // launch is an input-gradient convolution whose OUTPUT is the gradient g flowing into a training-
   // mode BatchNorm + PReLU; with that layer's forward input bx the epilogue accumulates the three
@@ -214,10 +219,15 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + (nt0 + j) * 16 + 4 * g);
+    if (p.bias2 && nt0 + j >= p.act_tiles)
+      bias4[j] = *reinterpret_cast<const f32x4*>(p.bias2 + (nt0 + j - p.act_tiles) * 16 + 4 * g);
+    else if (p.bias) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + (nt0 + j) * 16 + 4 * g);
   }
   const bool has_alpha = p.alpha != nullptr;
   const float alpha = has_alpha ? *p.alpha : 0.f;
+  // (workgroup-uniform) statistics rows: all channel tiles, or the first stats_tiles of a training pair
+  const bool do_stats = p.stats != nullptr && (p.stats_tiles == 0 || nt0 < p.stats_tiles);
+  const int stats_c = p.stats_tiles > 0 ? 16 * p.stats_tiles : p.Cout;
   f32x4 ssum[NT], ssq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
     for (int j = 0; j < NT; ++j) {
       f32x4 v = acc[i][j] + bias4[j];
       if (valid) {
-        if (p.stats) {
+        if (do_stats && (p.stats_tiles == 0 || nt0 + j < p.stats_tiles)) {
           ssum[j] += v;
           ssq[j] += v * v;
         }
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
       }
     }
   }
-  if (p.stats) {
+  if (do_stats) {
     __syncthreads();  // everyone is done with the staged tile
     float* red = reinterpret_cast<float*>(smem);  // [wave][2][NT*16]
 #pragma unroll
@@ -296,7 +306,8 @@ __global__ __launch_bounds__(256) void conv_fwd_mfma_kernel(ConvParams p) {
       float sacc = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sacc += red[(w * 2 + which) * NT * 16 + ch];
-      fin_store(&p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + nt0 * 16 + ch], sacc);
+      if (nt0 * 16 + ch < stats_c)
+        fin_store(&p.stats[((int64_t)blockIdx.x * 2 + which) * stats_c + nt0 * 16 + ch], sacc);
     }
     fin_tail_run<BnFin, 256, offsetof(ConvParams, ft), offsetof(ConvParams, bfin)>(p.stats, smem);
   }
@@ -313,7 +324,11 @@ static int launch_conv_cfg(ConvParams p, hipStream_t st) {
   dim3 grid((unsigned)nb, (unsigned)(p.Cout / (16 * NT)));
   constexpr int lds0 = G::LDS_BYTES > 4 * 2 * NT * 16 * 4 ? G::LDS_BYTES : 4 * 2 * NT * 16 * 4;
   p.fin_on = p.fin_on && p.stats;
-  const int lds = (int)fin_tail_arm(p, grid, 256, 2 * p.Cout, lds0);
+  // statistics of the first stats_tiles channel tiles only (training pair): those workgroups write the rows and
+  // take the tickets of the finalisation
+  const int stats_c = p.stats_tiles > 0 ? 16 * p.stats_tiles : p.Cout;
+  const dim3 sgrid(grid.x, (unsigned)cdiv(stats_c / 16, NT));
+  const int lds = (int)fin_tail_arm(p, sgrid, 256, 2 * stats_c, lds0);
   auto kern = conv_fwd_mfma_kernel<T, CK, KS, S, NT, TD, TH, TW>;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {

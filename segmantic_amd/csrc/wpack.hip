@@ -136,8 +136,10 @@ __global__ void wpack_batch_kernel(const segmi_wpack_desc* __restrict__ descs) {
       int co = nt * 16 + (lane & 15);
       float v = 0.f;
       if (tap < ntaps) {
-        if (d.kind == 0) v = w[((int64_t)co * d.cin_k + ch) * ntaps + tap];
-        else v = w[((int64_t)ch * d.cout_k + co) * ntaps + (ntaps - 1 - tap)];
+        if (d.kind == 0) {
+          if (d.w_src2 && co >= d.cout_split) v = d.w_src2[((int64_t)(co - d.cout_split) * d.cin_k + ch) * ntaps + tap];
+          else v = w[((int64_t)co * d.cin_k + ch) * ntaps + tap];
+        } else v = w[((int64_t)ch * d.cout_k + co) * ntaps + (ntaps - 1 - tap)];
         if (scale) v *= scale[co];
       }
       Elem<T>::st(out + e, v);
@@ -246,6 +248,8 @@ int segmi_wpack_batch(int dtype, const segmi_wpack_desc* descs_host, int ndesc,
     SEGMI_CHECK_ARG(d.kind >= 0 && d.kind <= 2, "wpack_batch[%d]: bad kind %d", i, d.kind);
     SEGMI_CHECK_ARG(d.ksize == 1 || d.ksize == 3, "wpack_batch[%d]: ksize must be 1 or 3", i);
     SEGMI_CHECK_ARG(d.kind != 2 || d.ksize == 3, "wpack_batch[%d]: transposed conv is k3 only", i);
+    SEGMI_CHECK_ARG(!d.w_src2 || (d.kind == 0 && d.cout_split > 0 && d.cout_split < d.cout_k),
+                    "wpack_batch[%d]: a second source needs kind 0 and 0 < cout_split < cout_k", i);
   }
   hipStream_t st = (hipStream_t)stream;
   if (upload) {

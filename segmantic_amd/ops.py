@@ -112,8 +112,9 @@ def wpack_bytes(dtype: torch.dtype, kind: int, cin_k: int, cout_k: int, ksize: i
 class WpackBatch:
     """Descriptor table for ``segmi_wpack_batch``: built once, re-run after every weight update.
 
-    ``entries`` = [(kind, w_src, scale_or_None, cin_k, cout_k, ksize), ...]; ``self.packed[i]``
-    is the device buffer entry ``i`` writes."""
+    ``entries`` = [(kind, w_src, scale_or_None, cin_k, cout_k, ksize[, w_src2, cout_split]), ...];
+    ``self.packed[i]`` is the device buffer entry ``i`` writes.  ``w_src2`` (kind 0): the source of the output
+    channels from ``cout_split`` on (the pair pack of ``conv3d_fwd_split_act`` out of two parameter tensors)."""
 
     def __init__(self, dtype: torch.dtype, entries):
         self.dtype = dtype
@@ -122,16 +123,23 @@ class WpackBatch:
         self._keep = []
         self._host = (_lib.WpackDesc * self.n)()
         dev = entries[0][1].device
-        for i, (kind, w, scale, cin_k, cout_k, ks) in enumerate(entries):
+        for i, ent in enumerate(entries):
+            kind, w, scale, cin_k, cout_k, ks = ent[:6]
+            w2, split = (ent[6], ent[7]) if len(ent) > 6 else (None, 0)
             nbytes = wpack_bytes(dtype, kind, cin_k, cout_k, ks)
             if nbytes <= 0:
                 raise ValueError(f"no MFMA pack for cin={cin_k} cout={cout_k}")
             out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self.packed.append(out)
-            self._keep.append((w, scale))
+            self._keep.append((w, scale, w2))
             d = self._host[i]
             _require_device(w)
             d.w_src, d.packed = w.data_ptr(), out.data_ptr()
+            if w2 is not None:
+                if kind != 0 or not 0 < split < cout_k:
+                    raise ValueError("WpackBatch: a second source needs kind 0 and 0 < cout_split < cout_k")
+                _require_device(w2)
+                d.w_src2, d.cout_split = w2.data_ptr(), int(split)
             d.scale = scale.data_ptr() if scale is not None else None
             d.kind, d.cin_k, d.cout_k, d.ksize = kind, cin_k, cout_k, ks
         self._dev = torch.empty(C.sizeof(_lib.WpackDesc) * self.n, dtype=torch.uint8, device=dev)
@@ -293,11 +301,15 @@ def conv3d_split_act_ok(x, y, ksize, stride) -> bool:
     return bool(lib.segmi_conv3d_split_act_ok(dtype_code(x), C.byref(ax), C.byref(ay), ksize, stride))
 
 
-def conv3d_fwd_split_act(x, y, packed, bias, prelu_alpha, act_channels, ksize, stride) -> None:
-    """one conv with two weight sets (concatenated pack): PReLU on the first ``act_channels`` only"""
+def conv3d_fwd_split_act(x, y, packed, bias, prelu_alpha, act_channels, ksize, stride, bias_b=None,
+                         stats=None, stats_fin=None) -> None:
+    """one conv with two weight sets (concatenated pack): PReLU on the first ``act_channels`` only.
+    Training: ``prelu_alpha`` None, ``bias_b`` = the second convolution's bias, ``stats`` (+ ``stats_fin``) =
+    BatchNorm statistics rows [conv3d_stats_rows][2][act_channels] of the first ``act_channels`` outputs."""
     ax, ay = act(x), act(y)
     check(lib.segmi_conv3d_fwd_split_act(dtype_code(x), C.byref(ax), C.byref(ay), _ptr(packed), _ptr(bias),
-                                         _ptr(prelu_alpha), act_channels, ksize, stride, _stream()),
+                                         _ptr(prelu_alpha), act_channels, ksize, stride, _ptr(bias_b),
+                                         _ptr(stats), _bn_fin(stats_fin), _stream()),
           "conv3d_fwd_split_act")
 
 

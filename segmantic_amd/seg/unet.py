@@ -164,6 +164,9 @@ class _Conv:
         self.gb = eng.grad(prefix + ".bias")
         self._packs: Dict[tuple, Tuple[int, Optional[torch.Tensor]]] = {}
         self._fold: Dict[str, tuple] = {}
+        # training pair (segmi_conv3d_fwd_split_act): the residual convolution of this first subunit's unit, when the
+        # two can run as ONE launch over a pack with both weight sets (set by UNetEngine._make_ru)
+        self.pair_with: Optional["_Conv"] = None
         eng._convs.append(self)
 
     @property
@@ -207,6 +210,22 @@ class _Conv:
 
     def dgrad_pack(self):
         return self._pack("dgrad", *self.dgrad_geom())
+
+    def pair_pack(self):
+        """[this conv's weight | pair_with's weight] along the output channels (re-packed with the others after every
+        optimiser step: ``UNetEngine._repack_all``, two sources per descriptor)"""
+        key = ("pair", self.eng.dtype)
+        ver = self.eng.weights_version
+        if self.eng._packed_version != ver:
+            self.eng._repack_all()
+        self.eng._await_packs()
+        hit = self._packs.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        cat = torch.cat([self.w, self.pair_with.w], 0).contiguous()
+        buf = ops.wpack(self.eng.dtype, 0, cat, self.cin, 2 * self.cout, self.k, out=hit[1] if hit is not None else None)
+        self._packs[key] = (ver, buf)
+        return buf
 
     # eval mode: BatchNorm folded into the weights (scale) and bias
     def folded(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]):
@@ -423,6 +442,9 @@ class UNetEngine:
                     kind, cin_k, cout_k, k = geom
                     entries.append((kind, conv.w, None, cin_k, cout_k, k))
                     slots.append((conv, (tag, self.dtype)))
+                if conv.pair_with is not None and self.pair_train and conv not in self._carry_convs:
+                    entries.append((0, conv.w, None, conv.cin, 2 * conv.cout, conv.k, conv.pair_with.w, conv.cout))
+                    slots.append((conv, ("pair", self.dtype)))
             self._wbatch = {c: ((ops.WpackBatch(self.dtype, e), sl) if e else (None, [])) for c, (e, sl) in groups.items()}
         for carried in (False, True):
             if carried and self._tail_packed_version == ver:
@@ -515,6 +537,10 @@ class UNetEngine:
         res = None
         if stride != 1 or cin != cout:
             res = _Conv(self, f"{prefix}.residual", cin, cout, 3 if stride != 1 else 1, stride)
+            c0, bn0 = units[0]
+            if (len(units) >= 2 and bn0 is not None and c0.mfma and res.mfma and c0.k == 3 and res.k == 3
+                    and c0.stride == res.stride == 2):
+                c0.pair_with = res
         return {"prefix": prefix, "units": units, "res": res, "cin": cin, "cout": cout,
                 "stride": stride}
 
@@ -599,6 +625,20 @@ class UNetEngine:
     # 58 and the 512^3 benchmark gains 8-9 % (22.9 vs 21.0 volumes/s, same process order, one box).
     # SEGMI_FUSE_EVAL_TOP=0 restores the two launches.
     fuse_eval_top = os.environ.get("SEGMI_FUSE_EVAL_TOP", "1") != "0"
+
+    # Training: the stride-2 first subunit and the residual convolution of an encoder unit read the same input; as
+    # two launches of the tile-at-a-time kernel they cost 54 + 54 us (16 -> 32 at 64^3, batch 8), 44 + 44 and 14 + 24
+    # one and two levels down.  The eval pairing with BatchNorm statistics on the first half (round 4) runs them as
+    # one launch each.  SEGMI_PAIR_TRAIN=0: two launches (A/B).
+    pair_train = os.environ.get("SEGMI_PAIR_TRAIN", "1") != "0"
+
+    def _train_pair(self, ru, x, oshape):
+        """the [.., 2c] buffer of the merged first subunit + residual convolution (training), or None"""
+        c0 = ru["units"][0][0]
+        if not self.pair_train or c0.pair_with is None or c0 in self._carry_convs:
+            return None
+        m = self._buf(f"{ru['prefix']}.tm", oshape + (2 * c0.cout,))
+        return m if ops.conv3d_split_act_ok(x, m, 3, c0.stride) else None
 
     def _merged_eval(self, ru, x, oshape):
         """(pack, bias, buffer) of the merged subunit-0 + residual convolution of a unit (inference,
@@ -790,10 +830,13 @@ class UNetEngine:
         # unit); it is independent of the conv-unit chain, so it runs on a side stream
         br = None
         paired = False
+        tpair = None
         if ru["res"] is not None:
             rc = ru["res"]
             paired = self._pair_ok(ru, x, out, f"{pre}.r0", (n, d, h, w))
-            if not paired:
+            if not paired and in_tf is None:
+                tpair = self._train_pair(ru, x, (n, d, h, w))
+            if not paired and tpair is None:
                 br = self._fork_branch()
                 with torch.cuda.stream(br) if br is not None else _NullCtx():
                     ops.conv3d_fwd(x, out, rc.fwd_pack(), rc.w, 0, rc.b, rc.k, rc.stride)
@@ -802,6 +845,30 @@ class UNetEngine:
             resid = x
         for i, (conv, bn) in enumerate(ru["units"]):
             last = i == nun - 1
+            if i == 0 and tpair is not None:
+                # MFMA layers: subunit 0 (+ its statistics) and the residual convolution as ONE launch with 2c
+                # outputs -- one staging of x instead of two; consumers read the halves as channel-slice views
+                m = tpair
+                r, resid = m[..., :conv.cout], m[..., conv.cout:]
+                rows = ops.conv3d_stats_rows(x, m, conv.k, conv.stride)
+                stats = self._fstat(rows, conv.cout)
+                fin = self._stats_fin(bn, r) if self.fuse_fin else None
+                self._timed(conv.prefix + ":fwd", ops.conv3d_fwd_split_act, x, m, conv.pair_pack(), conv.b, None,
+                            conv.cout, conv.k, conv.stride, bias_b=ru["res"].b, stats=stats, stats_fin=fin)
+                if fin is None:
+                    ops.bn_finalize(stats, rows, conv.cout, n * d * h * w, bn.gamma, bn.beta, bn.rm,
+                                    bn.rv, self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
+                saved[f"in{i}"] = cur
+                saved[f"r{i}"] = r
+                nconv = ru["units"][i + 1][0]
+                if self._tf_ok(r, r, nconv) and nconv.cin == conv.cout and nconv.cout == conv.cout:
+                    in_tf = (bn.scale, bn.shift, bn.alpha)
+                    cur = r
+                else:
+                    a = self._buf(f"{pre}.a{i}", (n, d, h, w, conv.cout))
+                    ops.bn_act_fwd(r, a, bn.scale, bn.shift, bn.alpha, dropout=bn.drop())
+                    cur = a
+                continue
             if i == 0 and paired:
                 # first layer: subunit 0 and the residual convolution share one staging of x
                 r = self._buf(f"{pre}.r{i}", (n, d, h, w, conv.cout))

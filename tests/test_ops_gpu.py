@@ -1438,6 +1438,58 @@ def test_bn_statistics_finalised_by_the_producing_launch(case, dtype):
         assert torch.equal(g_, g2), name + " not reproducible"
 
 
+@pytest.mark.parametrize("case", [(16, 32, (32, 34, 66), 2), (32, 64, (16, 32, 32), 2), (64, 128, (8, 16, 16), 3),
+                                  (16, 16, (16, 32, 64), 1)])
+def test_training_pair_of_a_residual_units_stride2_convolutions_is_the_two_launches(case):
+    """segmi_conv3d_fwd_split_act in training: the first subunit's convolution (with its BatchNorm statistics and
+    their finalisation) and the residual convolution of one input as ONE launch over a pack built from the two
+    parameter tensors (segmi_wpack_desc.w_src2) -- the output halves are the two launches' tensors bit for bit, the
+    statistics are those of the first half alone (same rows, same finalisation)."""
+    cin, c, sp, n = case
+    dtype = torch.bfloat16
+    xd = to_ndhwc(rnd((n, cin) + sp, 41), dtype)
+    wa = rnd((c, cin, 3, 3, 3), 42, 1.0 / math.sqrt(cin * 27)).to(DEV)
+    wb = rnd((c, cin, 3, 3, 3), 43, 1.0 / math.sqrt(cin * 27)).to(DEV)
+    ba, bb = rnd((c,), 44, 0.1).to(DEV), rnd((c,), 45, 0.1).to(DEV)
+    osp = tuple((v - 1) // 2 + 1 for v in sp)
+    count = n * osp[0] * osp[1] * osp[2]
+    gamma, beta = (1 + 0.2 * rnd((c,), 46)).to(DEV), (0.1 * rnd((c,), 47)).to(DEV)
+    m = torch.full((n,) + osp + (2 * c,), float("nan"), dtype=dtype, device=DEV)
+    if not ops.conv3d_split_act_ok(xd, m, 3, 2):
+        pytest.skip("another kernel family takes this layer")
+    # the two launches
+    ya = torch.empty((n,) + osp + (c,), dtype=dtype, device=DEV)
+    yb = torch.empty_like(ya)
+    rows = ops.conv3d_stats_rows(xd, ya, 3, 2)
+    stats = torch.zeros((rows, 2, c), device=DEV)
+    rm, rv, (mean, invstd, scale, shift) = _fin_bufs(c)
+    ops.conv3d_fwd(xd, ya, ops.wpack(dtype, 0, wa, cin, c, 3), wa, 0, ba, 3, 2, stats=stats,
+                   stats_fin=(count, gamma, beta, rm, rv, 0.1, 1e-5, mean, invstd, scale, shift))
+    ops.conv3d_fwd(xd, yb, ops.wpack(dtype, 0, wb, cin, c, 3), wb, 0, bb, 3, 2)
+    # one launch
+    batch = ops.WpackBatch(dtype, [(0, wa, None, cin, 2 * c, 3, wb, c)])
+    batch.run()
+    rows_m = ops.conv3d_stats_rows(xd, m, 3, 2)
+    stats_m = torch.zeros((rows_m, 2, c), device=DEV)
+    rm2, rv2, (mean2, invstd2, scale2, shift2) = _fin_bufs(c)
+    ops.conv3d_fwd_split_act(xd, m, batch.packed[0], ba, None, c, 3, 2, bias_b=bb, stats=stats_m,
+                             stats_fin=(count, gamma, beta, rm2, rv2, 0.1, 1e-5, mean2, invstd2, scale2, shift2))
+    torch.cuda.synchronize()
+    assert torch.equal(m[..., :c], ya) and torch.equal(m[..., c:], yb)
+    for a, b_, name in zip((mean, invstd, scale, shift, rm, rv), (mean2, invstd2, scale2, shift2, rm2, rv2),
+                           ("mean", "invstd", "scale", "shift", "running_mean", "running_var")):
+        assert bool(torch.isfinite(b_).all()), name
+        assert float((a - b_).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, name
+    # the pack of two sources is the pack of the concatenated weight
+    cat = ops.wpack(dtype, 0, torch.cat([wa, wb], 0).contiguous(), cin, 2 * c, 3)
+    assert torch.equal(cat, batch.packed[0])
+    # a bias table for both halves in one tensor (bias_b = None) gives the same tensor
+    m2 = torch.empty_like(m)
+    ops.conv3d_fwd_split_act(xd, m2, cat, torch.cat([ba, bb]).contiguous(), None, c, 3, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(m2, m)
+
+
 def test_bn_statistics_finalised_by_the_pair_launch():
     cin, cout, sp, n, s = 1, 16, (20, 34, 70), 2, 2
     dtype = torch.bfloat16
