@@ -43,6 +43,7 @@ struct WgradParams {
   unsigned long long* stamps;  // diag build: s_memtime stamps of workgroup 0, [iter][12 waves][4]
   int ci_chunks;
   int dbg;
+  int zmarch;     // wave-specialised kernel: shared input planes of consecutive z-tiles are copied LDS -> LDS (1 = on)
   // optional input transform of X (segmi_in_affine): the BatchNorm-apply + PReLU that produced the
   // forward input is applied while the X tile is committed to LDS (bf16 only)
   const float* in_scale;
