@@ -30,8 +30,11 @@
 // vector-memory pipe (~17-20 GB/s per CU here, 23 in an element-wise kernel), L2-side bytes, the 1.41x halo of the
 // 8 x 16 tile included: 1.29 GB, i.e. ~220 us at the element-wise rate.  DESIGN.md section 6 lists the variants that
 // were built and measured on the way (all correct, none faster): a 6-pair ring of 2-plane steps with four pairs in
-// flight, an L2 warm-up two steps ahead, lane-contiguous 16-byte stores through an LDS transpose, and a 512-thread
-// producer / consumer form on 16 x 16 columns.
+// flight, an L2 warm-up two steps ahead, lane-contiguous 16-byte stores through an LDS transpose, a 512-thread
+// producer / consumer form on 16 x 16 columns, and this very kernel with 8 waves on 16 x 16 columns (one workgroup per
+// CU, y halo 1.27 x instead of 1.41 x: 290 vs 277 us plain, 341 vs 342 with the input transform, 349 vs 343 / 376 vs
+// 376 as input gradient without / with the sums; step 4.64 vs 4.61 ms) -- fewer halo bytes do not pay for the lockstep
+// of a single workgroup per CU.
 // (A hazard met on the way: `buffer_store_dwordx4` with an SGPR soffset followed by a VALU write of its data
 // registers stored the NEW values in some lanes; hipcc pads that hazard only for stores without a register soffset.)
 //

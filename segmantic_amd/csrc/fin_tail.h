@@ -198,6 +198,8 @@ struct BnFin {
   float momentum, eps;
   float *mean, *invstd, *scale, *shift;
   __device__ void operator()(const double* sums, double*) const {
+    if (threadIdx.x >= 256) return;        // (workgroups of more than 256 threads: one thread per channel slot -- the
+                                           // running statistics are read-modify-written)
     for (int cc = threadIdx.x; cc < c; cc += 256) {
       const double m = sums[cc] / count;
       double var = sums[c + cc] / count - m * m;
