@@ -511,8 +511,11 @@ def main():
                              "hw_queues_set_before_runtime_init": bool(segmantic_amd.HW_QUEUES_EFFECTIVE),
                              "streams_created_before_this_leg": "training + weight-gradient (train leg of this run)"
                              if wl == "all" else "none"},
-                   "roofline": r["roofline"]}
+                   # per-kernel roofline: from the ONE-lane pass when there is one (beside copies of itself on other
+                   # lanes a launch's duration is not the kernel's)
+                   "roofline": (r2 if r2["lanes"] == 1 else r)["roofline"]}
             if inf["roofline"]:
+                inf["roofline"]["lanes_of_the_timed_pass"] = (r2 if r2["lanes"] == 1 else r)["lanes"]
                 inf["roofline"]["traffic"] = pmc_traffic("infer_top_conv_fwd_hbm_bytes_per_launch")
             if world > 1:
                 # ONE volume cut into z-slabs (north_star's inference split): every rank runs the windows

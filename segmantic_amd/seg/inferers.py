@@ -91,10 +91,17 @@ def default_lanes() -> int:
     cache, not to the lane count, and removed: `_cache_workspace`.  Two lanes now measure +1.5 .. +3 % whichever
     count is timed first, three lanes +5 % (`gpurun_out/r3/lanes_order.txt`, `lanes_n.txt`).  The default stays 1:
     with several lanes a launch's duration is that of two co-running launches, which makes per-kernel rooflines
-    of the line unreadable; `lanes=` / SEGMI_SW_LANES for throughput.)"""
+    of the line unreadable; `lanes=` / SEGMI_SW_LANES for throughput.)
+
+    Round 4: default 3.  With the forwards as they are now (GPU busy 41.3 of 41.9 ms per volume on one lane, but
+    the 16-window launches of the deep levels and the ramps of the 512-workgroup launches leave CUs idle inside
+    that time) three lanes take 39.6 ms per volume against 41.1 (2: 40.3, 4: 40.5; `gpurun_out/r4/sweep_063254.txt`),
+    labels bit-identical.  bench.py times the default and ALSO a one-lane pass, and takes the per-kernel roofline of
+    its inference object from the one-lane pass (a launch timed beside copies of itself says nothing about the
+    kernel); profiling scripts pin SEGMI_SW_LANES=1."""
     if os.environ.get("SEGMI_SERIAL"):
         return 1
-    return max(1, int(os.environ.get("SEGMI_SW_LANES", "1")))
+    return max(1, int(os.environ.get("SEGMI_SW_LANES", "3")))
 
 
 def _lane_streams(device, n: Optional[int] = None):
