@@ -309,7 +309,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         # that slab is blended (same kernel, same ordered sums: bit-identical) on a second stream while the
         # forwards of the following levels run.  The blend is HBM-bound, the forwards are issue-bound: of the
         # 6.1 ms the one-shot blend of a 512^3 volume takes, only the last slab's share stays exposed.
-        pipe = (into is not None and lanes is None and not partial and z_slab is None
+        pipe = (into is not None and not partial and z_slab is None
                 and len(per_dim[0]) >= 2 and os.environ.get("SEGMI_SW_PIPE_BLEND", "1") != "0")
         nyx = len(per_dim[1]) * len(per_dim[2])
         z_done, next_level = 0, 0
@@ -334,9 +334,12 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                         lab_p = torch.empty((orig[0], orig[1], orig[2]),
                                             dtype=torch.uint8 if K <= 256 else torch.int32, device=dev)
                 bs = _blend_stream(dev)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                bs.wait_event(ev)
+                # every window of the finished levels has been enqueued (groups go out in schedule order): the blend
+                # waits for the current tail of the stream(s) that run them -- the caller's, or every lane's
+                for src in (lanes if (lanes is not None and forked) else [main]):
+                    ev = torch.cuda.Event()
+                    ev.record(src)
+                    bs.wait_event(ev)
                 with torch.cuda.stream(bs):
                     ops.sw_blend(cache, [[s0 - z_done for s0 in per_dim_u[0]], per_dim_u[1], per_dim_u[2]], lo, hi,
                                  roi, z1 - z_done, orig[1], orig[2], importance=imp,
@@ -373,6 +376,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                         e1.record()
                         lane_events[lane].append((e0, e1))
                 if ok:
+                    blend_finished_levels(g0 + len(grp) - 1)
                     continue
                 if gi > 1:
                     raise RuntimeError("predictor stopped accepting forward_into mid-volume")
