@@ -348,6 +348,32 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                                  normalize=True)
                 z_done = z1
 
+        def pick_strategy(k, cdtype):
+            """deferred blend (every prediction kept until the ordered blend) or the streaming accumulator"""
+            nonlocal K, cache, deferred, acc, cnt
+            K = int(k)
+            need = (hi - lo) * nvox_roi * K * torch.empty((), dtype=cdtype).element_size()
+            cshape = (hi - lo, roi[0], roi[1], roi[2], K)
+            kept = _CACHE_WS.get(_cache_key(dev)) if dev.type == "cuda" else None
+            have = kept is not None and tuple(kept[0].shape) == cshape and kept[0].dtype == cdtype
+            deferred = blend != "stream" and max(len(v) for v in per_dim) <= 64 and (
+                blend == "deferred" or have or need <= _cache_budget_bytes(dev))
+            if deferred:
+                cache, busy = _cache_workspace(dev, cshape, cdtype)
+                if busy is not None:
+                    main.wait_event(busy)       # an earlier call's blend (any stream) still owns it
+            else:
+                acc = torch.zeros((1, orig[0], orig[1], orig[2], K), dtype=torch.float32, device=dev)
+                cnt = torch.zeros((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
+
+        # this build's own network says up front what it writes into the cache (``Net.cache_spec``): the first
+        # window group then goes straight into the cache like the others (it used to run through the generic
+        # path -- gather, forward, a 1 GB copy of its predictions into the cache -- to learn the class count)
+        spec = getattr(owner, "cache_spec", None)
+        spec = spec() if (callable(spec) and into is not None) else None
+        if spec is not None:
+            pick_strategy(*spec)
+
         for gi, g0 in enumerate(range(lo, hi, sw_batch_size)):
             grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
             slot = g0 - lo
@@ -405,21 +431,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
                 continue                                   # predicted straight into the cache
             pn = as_ndhwc(predictor(wview))
             if K is None:                                  # first group: pick the strategy
-                K = pn.shape[4]
-                need = (hi - lo) * nvox_roi * K * pn.element_size()
-                cshape = (hi - lo, roi[0], roi[1], roi[2], K)
-                kept = _CACHE_WS.get(_cache_key(dev)) if dev.type == "cuda" else None
-                have = kept is not None and tuple(kept[0].shape) == cshape and kept[0].dtype == pn.dtype
-                deferred = blend != "stream" and max(len(v) for v in per_dim) <= 64 and (
-                    blend == "deferred" or have or need <= _cache_budget_bytes(dev))
-                if deferred:
-                    cache, busy = _cache_workspace(dev, cshape, pn.dtype)
-                    if busy is not None:
-                        main.wait_event(busy)       # an earlier call's blend (any stream) still owns it
-                else:
-                    acc = torch.zeros((1, orig[0], orig[1], orig[2], K), dtype=torch.float32,
-                                      device=dev)
-                    cnt = torch.zeros((orig[0], orig[1], orig[2]), dtype=torch.float32, device=dev)
+                pick_strategy(pn.shape[4], pn.dtype)
             if deferred:
                 cache[slot:slot + len(grp)].copy_(pn)
                 blend_finished_levels(g0 + len(grp) - 1)

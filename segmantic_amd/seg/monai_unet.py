@@ -203,6 +203,16 @@ class Net(torch.nn.Module):
             eng.forward(x, train=False, out=out_ndhwc, lane=lane)
         return True
 
+    def cache_spec(self):
+        """(classes, dtype) of what ``forward_into`` writes per voxel, or None where it would refuse: lets the
+        sliding-window driver allocate its prediction cache before the first window group"""
+        if self.training or self.device.type != "cuda":
+            return None
+        eng = self._engine_for()
+        if eng.kpad != eng.net.out_channels:
+            return None
+        return eng.net.out_channels, eng.dtype
+
     def window_views_ok(self, dtype) -> bool:
         """sliding-window driver: may it hand ``forward_into`` an ``ops.WindowBatch`` (windows read in place)?"""
         if self.training or self.device.type != "cuda":
