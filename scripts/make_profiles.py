@@ -39,7 +39,7 @@ for wl, name in (("train", "train_b8_128_bf16"), ("infer", "infer_512_bf16")):
         steps = str(dt // 22 if dt and dt % 22 == 0 else sum(v for k, v in calls.items() if "sw_blend" in k) // 7)
     open(os.path.join(OUT, f"{tag}_{name}_kernel_stats.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload infer --steps 2 --warmup 1' if wl == 'infer' else '--workload train --steps 10 --warmup 3'} --no-cpu-baseline\n"
-        f"# ({'both streams overlapped' if wl == 'train' else 'one lane (the default)'}; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
+        f"# ({'both streams overlapped' if wl == 'train' else 'one lane (SEGMI_SW_LANES=1 pinned for per-kernel times; the library default is 3)'}; every launch of the run = {steps} steps incl. warm-up; setup kernels included)\n"
         + run("kstats.py", st, steps))
 shutil.copy(os.path.join(SRC, "bench_all.json"), os.path.join(OUT, f"{tag}_bench_all.json"))
 
