@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--volume", type=int, default=512, help="infer: cubic volume extent")
     ap.add_argument("--overlap", type=float, default=0.5)
     ap.add_argument("--sw-batch", type=int, default=4, help="infer: windows per predictor call")
-    ap.add_argument("--infer-steps", type=int, default=3)
+    ap.add_argument("--infer-steps", type=int, default=10,
+                    help="infer leg of --workload all: timed volumes per lane count (10 x ~40 ms; 3 until round 4: the ramp of the first and the exposed tail of the last volume were a third of the sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lane-ab", action="store_true", help="infer: only the default lane count (profiling runs)")
     ap.add_argument("--cpu-size", type=int, default=128)
@@ -370,7 +371,8 @@ def run_fit(args, rank, device, barrier, steps, warmup):
     V = max(args.size + 32, 160)
     cache = trainer.CachedVolumes.__new__(trainer.CachedVolumes)
     cache.items, cache.device = [], torch.device(device)
-    cache._stream = torch.cuda.Stream(device=device)
+    from segmantic_amd.seg import streams as _streams
+    cache._stream = _streams.shared_stream(device, _streams.AUX)
     cache._pinned = torch.empty(4096, dtype=torch.int64).pin_memory()
     for v in range(4):
         img, lab = synthetic(1, V, K, 10 + v, device)

@@ -15,6 +15,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import streams
+
 
 def env_world() -> tuple:
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -71,7 +73,7 @@ class GradSync:
         self.n = flat_grad.numel()
         self._hi = self.n          # everything in [_hi, n) has been launched
         self._works: List = []
-        self._side = torch.cuda.Stream() if flat_grad.is_cuda else None
+        self._side = streams.shared_stream(flat_grad.device, streams.EXCHANGE) if flat_grad.is_cuda else None
         # SEGMI_GRADSYNC_FORCE=1: issue the collectives even with one rank (a sum over one rank is the
         # identity) -- lets a one-GPU box run the whole RCCL path: side stream, events, Work.wait()
         self._force = os.environ.get("SEGMI_GRADSYNC_FORCE") == "1" and dist.is_initialized()

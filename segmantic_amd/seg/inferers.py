@@ -24,6 +24,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 from .. import ops
+from . import streams
 from .losses import as_ndhwc
 
 
@@ -75,7 +76,6 @@ class SlidingWindowResult:
         self.logits, self.labels, self.count = logits, labels, count
 
 
-_LANES: dict = {}
 
 
 def default_lanes() -> int:
@@ -110,20 +110,14 @@ def _lane_streams(device, n: Optional[int] = None):
     n = default_lanes() if n is None else int(n)
     if n < 2:
         return None
-    key = (torch.device(device).index, n)
-    if key not in _LANES:
-        _LANES[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-    return _LANES[key]
+    # the package's shared side streams (seg/streams.py): slots 0 .. 2, then 4 + (slot 3 is the blend's)
+    return [streams.shared_stream(device, i if i < streams.BLEND else i + 1) for i in range(n)]
 
 
-_BLEND_STREAMS: dict = {}
 
 
 def _blend_stream(device):
-    key = torch.device(device).index
-    if key not in _BLEND_STREAMS:
-        _BLEND_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _BLEND_STREAMS[key]
+    return streams.shared_stream(device, streams.BLEND)
 
 
 def group_factor() -> int:

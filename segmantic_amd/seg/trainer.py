@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from . import streams
 from .augment import draw_intensity, draw_spatial, forward_point, to_index_map_xyz
 from .distributed import broadcast_buffers, env_world, init_distributed
 from .pipeline import PredictPipeline
@@ -39,7 +40,7 @@ class CachedVolumes:
         pipe = PredictPipeline(device=device, spacing=spacing, with_label=True, label_nearest=label_nearest)
         self.items = []
         self.device = torch.device(device)
-        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream = streams.shared_stream(self.device, streams.AUX)
         self._pinned = torch.empty(4096, dtype=torch.int64).pin_memory()
         for f in files:
             it = pipe.load(f["image"], f["label"])
@@ -191,7 +192,7 @@ class BatchPrefetcher:
     def __init__(self, net, cache: CachedVolumes):
         self.net, self.cache = net, cache
         self.enabled = os.environ.get("SEGMI_PREFETCH", "0") == "1"
-        self.stream = torch.cuda.Stream(device=cache.device) if self.enabled else None
+        self.stream = streams.shared_stream(cache.device, streams.AUX) if self.enabled else None
         self._sets: List[Optional[Dict]] = [None, None]
         self._released: List[Optional[torch.cuda.Event]] = [None, None]
         self._turn = 0

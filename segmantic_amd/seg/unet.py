@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from . import streams
 
 
 # =============================================================================================
@@ -1311,7 +1312,7 @@ class UNetEngine:
 
     def _pack_stream(self):
         if self._packs_stream is None:
-            self._packs_stream = torch.cuda.Stream(device=self.device)
+            self._packs_stream = streams.shared_stream(self.device, streams.PACK)
         return self._packs_stream
 
     def finish_carried(self, update_suffix, new_version: int):
@@ -1376,7 +1377,7 @@ class UNetEngine:
             if self._side_cus:
                 self._side = ops.cu_masked_stream(self._side_cus, self.device)
             else:
-                self._side = torch.cuda.Stream(device=self.device)
+                self._side = streams.shared_stream(self.device, streams.WGRAD)
         return self._side
 
     # residual-branch overlap on a second side stream: measured neutral on MI355X (the branch
@@ -1444,7 +1445,7 @@ class UNetEngine:
         if not self.overlap_branches:
             return None
         if self._side2 is None:
-            self._side2 = torch.cuda.Stream(device=self.device)
+            self._side2 = streams.shared_stream(self.device, streams.AUX)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._side2.wait_event(ev)
