@@ -477,8 +477,10 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         logits = (torch.cat(outs, 0) if B > 1 else outs[0]).permute(0, 4, 1, 2, 3)
     if not return_labels:
         return logits
-    labels = None if labs[0] is None else torch.stack(labs).unsqueeze(1)
-    return SlidingWindowResult(logits, labels, torch.stack(cnts))
+    # (one volume: views, not copies -- the count map of a 512^3 volume is 537 MB)
+    one = B == 1
+    labels = None if labs[0] is None else (labs[0][None] if one else torch.stack(labs)).unsqueeze(1)
+    return SlidingWindowResult(logits, labels, cnts[0][None] if one else torch.stack(cnts))
 
 
 def z_slabs(depth: int, world: int) -> List[Tuple[int, int]]:
