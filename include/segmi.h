@@ -73,8 +73,10 @@ typedef struct segmi_wpack_desc {
   const float* scale;  /* device f32[cout_k] or NULL                                 */
   void* packed;        /* device destination, segmi_wpack_bytes(...) bytes            */
   int32_t kind, cin_k, cout_k, ksize;
-  /* kind 0 only: output channels >= cout_split come from a second source [cout_k - cout_split][cin_k][taps]
-   * (the pair pack of segmi_conv3d_fwd_split_act out of two separate parameter tensors); NULL = one source */
+  /* kind 0: output channels >= cout_split come from a second source [cout_k - cout_split][cin_k][taps] (the pair
+   * pack of segmi_conv3d_fwd_split_act out of two separate parameter tensors); kind 2: INPUT channels >= cout_split
+   * come from the second source [cin_k - cout_split][cout_k][27] (the paired input gradient of those two
+   * convolutions: one transposed convolution over their concatenated output gradients); NULL = one source */
   const float* w_src2;
   int32_t cout_split, reserved;
 } segmi_wpack_desc;

@@ -111,7 +111,13 @@ __global__ void wpack_batch_kernel(const segmi_wpack_desc* __restrict__ descs) {
         if (tap < nt_p) {
           int kd, kh, kw, dd, dh, dw;
           ct_tap(p, tap, kd, kh, kw, dd, dh, dw);
-          v = w[((int64_t)ch * d.cout_k + co) * 27 + (kd * 3 + kh) * 3 + kw];
+          // (two sources: the INPUT channels of the transposed convolution from cout_split on come from w_src2 --
+          // the paired input gradient of two stride-2 convolutions of one input, whose forward weights
+          // [c][cin][27] stack along this axis)
+          if (d.w_src2 && ch >= d.cout_split)
+            v = d.w_src2[((int64_t)(ch - d.cout_split) * d.cout_k + co) * 27 + (kd * 3 + kh) * 3 + kw];
+          else
+            v = w[((int64_t)ch * d.cout_k + co) * 27 + (kd * 3 + kh) * 3 + kw];
           if (scale) v *= scale[co];
         }
         Elem<T>::st(out + base + e, v);
@@ -248,8 +254,10 @@ int segmi_wpack_batch(int dtype, const segmi_wpack_desc* descs_host, int ndesc,
     SEGMI_CHECK_ARG(d.kind >= 0 && d.kind <= 2, "wpack_batch[%d]: bad kind %d", i, d.kind);
     SEGMI_CHECK_ARG(d.ksize == 1 || d.ksize == 3, "wpack_batch[%d]: ksize must be 1 or 3", i);
     SEGMI_CHECK_ARG(d.kind != 2 || d.ksize == 3, "wpack_batch[%d]: transposed conv is k3 only", i);
-    SEGMI_CHECK_ARG(!d.w_src2 || (d.kind == 0 && d.cout_split > 0 && d.cout_split < d.cout_k),
-                    "wpack_batch[%d]: a second source needs kind 0 and 0 < cout_split < cout_k", i);
+    SEGMI_CHECK_ARG(!d.w_src2 || (d.kind == 0 && d.cout_split > 0 && d.cout_split < d.cout_k) ||
+                        (d.kind == 2 && d.cout_split > 0 && d.cout_split < d.cin_k),
+                    "wpack_batch[%d]: a second source needs kind 0 with 0 < cout_split < cout_k or kind 2 with 0 < "
+                    "cout_split < cin_k", i);
   }
   hipStream_t st = (hipStream_t)stream;
   if (upload) {

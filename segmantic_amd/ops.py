@@ -136,8 +136,9 @@ class WpackBatch:
             _require_device(w)
             d.w_src, d.packed = w.data_ptr(), out.data_ptr()
             if w2 is not None:
-                if kind != 0 or not 0 < split < cout_k:
-                    raise ValueError("WpackBatch: a second source needs kind 0 and 0 < cout_split < cout_k")
+                if not ((kind == 0 and 0 < split < cout_k) or (kind == 2 and 0 < split < cin_k)):
+                    raise ValueError("WpackBatch: a second source needs kind 0 (0 < split < cout_k) or kind 2 "
+                                     "(0 < split < cin_k)")
                 _require_device(w2)
                 d.w_src2, d.cout_split = w2.data_ptr(), int(split)
             d.scale = scale.data_ptr() if scale is not None else None

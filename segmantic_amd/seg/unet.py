@@ -228,6 +228,22 @@ class _Conv:
         self._packs[key] = (ver, buf)
         return buf
 
+    def pair_dgrad_pack(self):
+        """input-gradient operand of the pair: ONE transposed convolution over [dy of this conv | dy of pair_with]
+        (2 cout input channels)"""
+        key = ("pair_dgrad", self.eng.dtype)
+        ver = self.eng.weights_version
+        if self.eng._packed_version != ver:
+            self.eng._repack_all()
+        self.eng._await_packs()
+        hit = self._packs.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        cat = torch.cat([self.w, self.pair_with.w], 0).contiguous()
+        buf = ops.wpack(self.eng.dtype, 2, cat, 2 * self.cout, self.cin, 3, out=hit[1] if hit is not None else None)
+        self._packs[key] = (ver, buf)
+        return buf
+
     # eval mode: BatchNorm folded into the weights (scale) and bias
     def folded(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]):
         ver = self.eng.weights_version
@@ -446,6 +462,9 @@ class UNetEngine:
                 if conv.pair_with is not None and self.pair_train and conv not in self._carry_convs:
                     entries.append((0, conv.w, None, conv.cin, 2 * conv.cout, conv.k, conv.pair_with.w, conv.cout))
                     slots.append((conv, ("pair", self.dtype)))
+                    if self.pair_bwd:
+                        entries.append((2, conv.w, None, 2 * conv.cout, conv.cin, 3, conv.pair_with.w, conv.cout))
+                        slots.append((conv, ("pair_dgrad", self.dtype)))
             self._wbatch = {c: ((ops.WpackBatch(self.dtype, e), sl) if e else (None, [])) for c, (e, sl) in groups.items()}
         for carried in (False, True):
             if carried and self._tail_packed_version == ver:
@@ -632,6 +651,26 @@ class UNetEngine:
     # one and two levels down.  The eval pairing with BatchNorm statistics on the first half (round 4) runs them as
     # one launch each.  SEGMI_PAIR_TRAIN=0: two launches (A/B).
     pair_train = os.environ.get("SEGMI_PAIR_TRAIN", "1") != "0"
+    # ... and their input gradients as ONE transposed convolution over the two output gradients, which then live in
+    # the halves of one [.., 2c] buffer: the BatchNorm backward of subunit 0 writes the first half, the producer of
+    # the unit's output gradient (the level below) the second.  SEGMI_PAIR_BWD=0: two launches.
+    pair_bwd = pair_train and os.environ.get("SEGMI_PAIR_BWD", "1") != "0"
+
+    def _pair_grad_buf(self, ru, shape):
+        """[.., 2c] gradient buffer of a unit whose forward ran paired (this step), else None"""
+        c0 = ru["units"][0][0]
+        sv = self._saved.get(ru["prefix"])
+        if not self.pair_bwd or c0.pair_with is None or sv is None or not sv.get("tpair"):
+            return None
+        return self._buf(f"{ru['prefix']}.mg", tuple(shape[:4]) + (2 * c0.cout,))
+
+    def _dout_slot(self, ru, name, shape):
+        """where the gradient of a residual unit's OUTPUT is to be written: the second half of the unit's pair
+        buffer when its two stride-2 input gradients run as one launch, else the plain buffer `name`"""
+        mg = self._pair_grad_buf(ru, shape)
+        if mg is not None and shape[4] == ru["units"][0][0].cout:
+            return mg[..., shape[4]:]
+        return self._buf(name, shape)
 
     def _train_pair(self, ru, x, oshape):
         """the [.., 2c] buffer of the merged first subunit + residual convolution (training), or None"""
@@ -884,6 +923,7 @@ class UNetEngine:
                                     bn.rv, self.momentum, self.eps, bn.mean, bn.invstd, bn.scale, bn.shift)
                 saved[f"in{i}"] = cur
                 saved[f"r{i}"] = r
+                saved["tpair"] = True
                 nconv = ru["units"][i + 1][0]
                 if self._tf_ok(r, r, nconv) and nconv.cin == conv.cout and nconv.cout == conv.cout:
                     in_tf = (bn.scale, bn.shift, bn.alpha)
@@ -933,10 +973,16 @@ class UNetEngine:
         x = sv["x"]
         nun = len(ru["units"])
         rc = ru["res"]
+        # paired input gradients: dout is the second half of the unit's [.., 2c] gradient buffer (the caller got it
+        # from _dout_slot), subunit 0's BatchNorm backward writes the first half, ONE transposed convolution over the
+        # buffer replaces the two input-gradient launches
+        mg = self._pair_grad_buf(ru, dout.shape) if (rc is not None and dx is not None) else None
+        if mg is not None and dout.data_ptr() != mg[..., dout.shape[4]:].data_ptr():
+            mg = None
         # the residual conv's input gradient depends only on dout: side stream, joined before
         # the first unit's dgrad accumulates on top of it
         br = None
-        if rc is not None and dx is not None:
+        if rc is not None and dx is not None and mg is None:
             br = self._fork_branch()
             with torch.cuda.stream(br) if br is not None else _NullCtx():
                 self._dgrad(rc, dout, dx, residual=extra)
@@ -947,7 +993,7 @@ class UNetEngine:
             xin = sv[f"in{i}"]
             if bn is not None:
                 r = sv[f"r{i}"]
-                dr = self._buf(f"{pre}.dr{i}", r.shape)
+                dr = mg[..., :r.shape[4]] if (mg is not None and i == 0) else self._buf(f"{pre}.dr{i}", r.shape)
                 self._bn_bwd(bn, g, r, dr, sums_rows=g_rows)
             else:
                 dr = g
@@ -971,6 +1017,9 @@ class UNetEngine:
         if dx is None:
             return 0
         conv0 = ru["units"][0][0]
+        if mg is not None:
+            ops.convT3d_fwd(mg, dx, conv0.pair_dgrad_pack(), None, None, residual=extra)
+            return 0
         bsum = dx_bn if dx_bn is not None and self._bsum_ok(conv0, first_dr, dx, dx_bn[0]) else None
         if rc is not None:
             self._join_branch(br)
@@ -1125,7 +1174,7 @@ class UNetEngine:
         if not conv_done:
             self._dgrad(up, du, dcat)
         d_down, d_sub = dcat[..., :c], dcat[..., c:]
-        dsum = self._buf(f"{p}ddown", (cat.shape[0], cat.shape[1], cat.shape[2], cat.shape[3], c))
+        dsum = self._dout_slot(lvl["down"], f"{p}ddown", (cat.shape[0], cat.shape[1], cat.shape[2], cat.shape[3], c))
         if lvl["sub"] is not None:
             self._level_bwd(lvl["sub"], d_sub, dx=dsum, extra=d_down)
         else:

@@ -1483,6 +1483,20 @@ def test_training_pair_of_a_residual_units_stride2_convolutions_is_the_two_launc
     # the pack of two sources is the pack of the concatenated weight
     cat = ops.wpack(dtype, 0, torch.cat([wa, wb], 0).contiguous(), cin, 2 * c, 3)
     assert torch.equal(cat, batch.packed[0])
+    # the paired INPUT gradient: one transposed convolution over [dy_a | dy_b] with the kind-2 pack of the two
+    # sources = the sum of the two input gradients (f32 accumulation over 2c channels instead of two bf16-rounded
+    # launches: tolerance), and that pack is the pack of the concatenated weight
+    bd = ops.WpackBatch(dtype, [(2, wa, None, 2 * c, cin, 3, wb, c)])
+    bd.run()
+    assert torch.equal(ops.wpack(dtype, 2, torch.cat([wa, wb], 0).contiguous(), 2 * c, cin, 3), bd.packed[0])
+    dy = to_ndhwc(rnd((n, 2 * c) + osp, 48), dtype)
+    dx_pair = torch.full_like(xd, float("nan"))
+    ops.convT3d_fwd(dy, dx_pair, bd.packed[0], None, None)
+    dx_two = torch.empty_like(xd)
+    ops.convT3d_fwd(dy[..., c:], dx_two, ops.wpack(dtype, 2, wb, c, cin, 3), None, None)
+    ops.convT3d_fwd(dy[..., :c], dx_two, ops.wpack(dtype, 2, wa, c, cin, 3), None, None, residual=dx_two)
+    torch.cuda.synchronize()
+    assert relerr(from_ndhwc(dx_pair), from_ndhwc(dx_two)) < BF16_RTOL
     # a bias table for both halves in one tensor (bias_b = None) gives the same tensor
     m2 = torch.empty_like(m)
     ops.conv3d_fwd_split_act(xd, m2, cat, torch.cat([ba, bb]).contiguous(), None, c, 3, 2)
