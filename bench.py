@@ -562,7 +562,7 @@ def main():
             out["f32_parity_mode"] = {
                 "what": "the same training step with f32 storage and exact-f32 MFMA chains (mixed_precision: false): "
                         "the mode whose logits meet north_star's 1e-3 tolerance against the CPU oracle "
-                        "(tests/test_unet_gpu.py asserts 2e-4); the bf16 headline path is gated at 6e-2 / 97 % argmax",
+                        "(tests/test_unet_gpu.py asserts 2e-4); the bf16 headline path is gated at 2e-2 / 98.5 % argmax (measured 7e-3 .. 9e-3 / 99.2 % at 32^3 .. 128^3)",
                 "value": r["units"] / r["dt"], "unit": "voxels/s", "ms_per_step": r["dt"] / n * 1e3, "steps": n,
                 "dtype": "f32", "roofline": r["roofline"]}
             del r

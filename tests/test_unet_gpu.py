@@ -134,13 +134,16 @@ def test_bf16_path_close_to_f32_oracle(train):
     torch.cuda.synchronize()
     assert out.dtype == torch.bfloat16
     err = rel(out.float().cpu(), out_ref)
-    assert err < 6e-2, err     # bf16 storage through 17 normalised layers (reported, not the parity gate)
+    # bf16 storage through 17 normalised layers (reported, not the parity gate).  Measured in round 4 over three
+    # seeds: training mode 7.4e-3 .. 9.0e-3 / 99.2 % / loss within 5.5e-6, eval 5.6e-3 .. 6.1e-3 / 99.4 %; the gates
+    # (6e-2 / 97 % / 2e-2 until then) are those numbers + margin, as at 64^3 / 128^3 below
+    assert err < 2e-2, err
     agree = float((torch.argmax(out.float().cpu(), 1) == torch.argmax(out_ref, 1)).float().mean())
-    assert agree > 0.97, agree
+    assert agree > 0.985, agree
     if train:
         res = net.training_step({"image": img.to(DEV), "label": lab.to(DEV)})
         torch.cuda.synchronize()
-        assert abs(float(res["loss"].cpu()) - float(ref_dice_loss(out_ref, lab))) < 2e-2
+        assert abs(float(res["loss"].cpu()) - float(ref_dice_loss(out_ref, lab))) < 1e-4
 
 
 @pytest.mark.parametrize("size", [64, 128])
