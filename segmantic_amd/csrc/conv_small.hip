@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   typedef typename std::conditional<ES == 2, u32x2, f32x4>::type Vec4;
   constexpr int GPR = XW / 4, NGRP = NROWS * GPR, NITV = (NGRP + 255) / 256;
   Vec4 vstg[CIN == 1 ? NITV : 1];
+  unsigned vok = 0u;                                   // bit k: vstg[k] lies inside the volume
   const bool vec = CIN == 1 && p.vec;
   if (vec) {
     const int64_t sy = win ? p.wsy : p.Wi, sz = win ? p.wsz : (int64_t)p.Hi * p.Wi;
@@ -108,15 +109,15 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
       const int row = gi / GPR, gq = gi % GPR;
       const int hy = row % HH, hz = row / HH;
       const int x0 = ix0 - 3 + 4 * gq;
-      vstg[k] = Vec4{};
-      if (gi < NGRP && (unsigned)(iz0 + hz) < (unsigned)p.Di && (unsigned)(iy0 + hy) < (unsigned)p.Hi &&
-          (unsigned)x0 < (unsigned)p.Wi)
-        vstg[k] = *reinterpret_cast<const Vec4*>(tile + hz * sz + hy * sy + (4 * gq - 3));
-    }
-#pragma unroll
-    for (int k = 0; k < NITV; ++k) {
-      const int gi = tid + 256 * k;
-      if (gi < NGRP) *reinterpret_cast<Vec4*>(xs + 4 * gi) = vstg[k];
+      // No branch around the load: a conditional load compiles to an exec-mask region with its own
+      // `s_waitcnt vmcnt(0)`, i.e. the six loads of a thread went out ONE AFTER THE OTHER (six global-memory
+      // latencies in front of every tile's 16 MFMAs; round 4).  Lanes outside the volume read the tensor's first
+      // element group instead (always there, aligned) and drop it.
+      const bool ok = (gi < NGRP) & ((unsigned)(iz0 + hz) < (unsigned)p.Di) & ((unsigned)(iy0 + hy) < (unsigned)p.Hi) &
+                      ((unsigned)x0 < (unsigned)p.Wi);
+      const T* src = ok ? tile + hz * sz + hy * sy + (4 * gq - 3) : (const T*)p.in;
+      vstg[k] = *reinterpret_cast<const Vec4*>(src);      // (zeroed where !ok when it goes to LDS: no use of the value here)
+      vok |= ok ? (1u << k) : 0u;
     }
   } else {
     static_assert(RPI <= HH, "at most one row wrap per iteration");
@@ -126,10 +127,12 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
     int off = hz * sz + hy * sy + hx * p.ldi + row / (HH * HD);
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      stg[k] = (T)0;
-      if (xlive && row < NROWS && (unsigned)(iz0 + hz) < (unsigned)p.Di &&
-          (unsigned)(iy0 + hy) < (unsigned)p.Hi)
-        stg[k] = tile[off];
+      {
+        const bool ok = xlive & (row < NROWS) & ((unsigned)(iz0 + hz) < (unsigned)p.Di) & ((unsigned)(iy0 + hy) < (unsigned)p.Hi);
+        const T* src = ok ? tile + off : (const T*)p.in;          // (no branch around the load, as above)
+        const T got = *src;
+        stg[k] = ok ? got : (T)0;
+      }
       row += RPI;
       hy += RPI;
       off += RPI * sy;
@@ -138,13 +141,6 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
         off += sz - HH * sy;
         if (++hz == HD) { hz = 0; off += 1 - HD * sz; }   // next input channel
       }
-    }
-  }
-  if (!vec && tid < RPI * HW) {
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int row = tid / HW + RPI * k;
-      if (row < NROWS) xs[row * XW + 3 + hx] = stg[k];
     }
   }
   // ---- weight operand: lane (co = r, g) holds k = KSTEP*s + KG*g + j; the halo offset of that k
@@ -196,6 +192,21 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(SmallConvParams p) 
   float alpha = has_alpha ? *p.alpha : 0.f;
   touch_v(bias4);
   touch_s(alpha);
+  // ---- the staged halo -> LDS, only now: the weight / bias loads above are in flight beside the halo loads instead
+  // of behind their wait
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < NITV; ++k) {
+      const int gi = tid + 256 * k;
+      if (gi < NGRP) *reinterpret_cast<Vec4*>(xs + 4 * gi) = ((vok >> k) & 1u) ? vstg[k] : Vec4{};
+    }
+  } else if (tid < RPI * HW) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int row = tid / HW + RPI * k;
+      if (row < NROWS) xs[row * XW + 3 + hx] = stg[k];
+    }
+  }
   __syncthreads();
 
   // ---- wave w computes plane z = w of the tile; voxel tile i = row y = i (x = r).  The 8 rows are done in
