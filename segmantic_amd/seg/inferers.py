@@ -371,7 +371,19 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size: Sequence[int], sw_b
         for gi, g0 in enumerate(range(lo, hi, sw_batch_size)):
             grp = wins_u[g0:min(g0 + sw_batch_size, hi)]
             slot = g0 - lo
-            if cache is not None and into is not None and lanes is not None:
+            # the first forward after a weight change builds the eval packs (folded BatchNorm, merged pairs) on the
+            # stream it runs on: it stays on the caller's stream, in front of the fork, so that no lane can read a
+            # pack that is still being written (round 4: with the cache allocated up front group 0 had moved to
+            # lane 0 and a z-slab parity test failed once in a while)
+            cold = False
+            if lanes is not None and gi == 0 and callable(getattr(owner, "eval_state", None)):
+                state = owner.eval_state()
+                cold = getattr(owner, "_sw_warm_state", None) != state
+                try:
+                    owner._sw_warm_state = state          # (kept on the network object: dies with it)
+                except AttributeError:
+                    cold = True
+            if cache is not None and into is not None and lanes is not None and not cold:
                 # window groups are independent once their predictions go to the cache: alternate
                 # them over two streams (each with its own activation lane of the engine) so the
                 # small deep layers of one group overlap the wide layers of the other

@@ -213,6 +213,13 @@ class Net(torch.nn.Module):
             return None
         return eng.net.out_channels, eng.dtype
 
+    def eval_state(self):
+        """(engine identity, weights version): the sliding-window driver runs the FIRST window group after a change
+        of it on the caller's stream before it forks its lanes -- that forward builds the folded / merged weight packs
+        every lane then reads"""
+        eng = self._engine_for()
+        return id(eng), eng.weights_version
+
     def window_views_ok(self, dtype) -> bool:
         """sliding-window driver: may it hand ``forward_into`` an ``ops.WindowBatch`` (windows read in place)?"""
         if self.training or self.device.type != "cuda":
