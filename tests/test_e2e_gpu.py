@@ -147,6 +147,7 @@ def test_sliding_window_image_smaller_than_roi_and_inferer_class():
 def test_full_size_properties_128_bf16():
     """BASELINE-size checks through size-independent properties: batch items are independent in
     eval mode, sliding-window of a single-window volume equals the plain forward, logits finite."""
+    torch.manual_seed(128)          # (own seed for the initialisation: see test_full_size_c4_160_k32_training_step_bf16)
     net = Net(num_classes=16).to(DEV).eval()
     net.mixed_precision = True
     g = torch.Generator().manual_seed(0)
@@ -634,6 +635,9 @@ def test_full_size_c3_512_sliding_window_bf16():
 
 
 def test_full_size_c4_160_k32_training_step_bf16():
+    # (its own seed: "the loss falls within five steps" is a property of a sane initialisation, not of whatever state
+    # the tests before it left in the global generator -- the test failed once in six full-suite runs in round 4)
+    torch.manual_seed(160)
     net = Net(num_classes=32).to(DEV).train()
     net.mixed_precision = True
     g = torch.Generator().manual_seed(4)
@@ -646,6 +650,7 @@ def test_full_size_c4_160_k32_training_step_bf16():
     logits = eng._bufs["logits.t"]
     assert tuple(logits.shape) == (2, 160, 160, 160, 32) and logits.dtype == torch.bfloat16
     assert bool(torch.isfinite(logits.float()).all())
+    torch.cuda.synchronize()        # the carried weight gradients of the step are still being written otherwise
     assert bool(torch.isfinite(eng.flat_grad).all()) and float(eng.flat_grad.abs().max()) > 0
     # the 32 -> 32 full-resolution layer takes the ring kernel (its live timing exists)
     assert len(eng.timing_ms("2.1.conv.unit0.conv:fwd")) == 1
